@@ -1,0 +1,194 @@
+/* msq_abi.h -- C ABI of the MI355X (gfx950) pileup + Fisher layer behind juliet's MSA / AminoAcidCaller
+ * interface.  Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Every entry point returns an int status (0 = MSQ_OK, <0 = error) and never throws; msq_last_error()
+ * gives the text for the calling thread.  One msq_ctx per (process, GPU); calls on one context are
+ * serialised by the caller.  Unless a function says "host", pointer arguments named d_* are DEVICE
+ * pointers (hipMalloc'd by the caller, e.g. a torch tensor's data_ptr()) and the work is enqueued on the
+ * context's stream (msq_ctx_set_stream) without synchronising.
+ *
+ * All reference citations are file:line under the reference tree (PacBio MinorSeq 1.10.0).
+ */
+#ifndef MSQ_ABI_H
+#define MSQ_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum msq_status {
+    MSQ_OK = 0,
+    MSQ_ERR_ARG = -1,      /* bad argument (NULL, negative size, misaligned offset ...) */
+    MSQ_ERR_HIP = -2,      /* a HIP runtime call failed */
+    MSQ_ERR_CIGAR = -3,    /* std::runtime_error("Unexpected cigar ...")  src/MSA.cpp:182 */
+    MSQ_ERR_BASE = -4,     /* std::runtime_error("Unexpected base ...")   src/MSA.cpp:85  */
+    MSQ_ERR_WINDOW = -5,   /* a read reaches outside [win_begin0, win_begin0+W): assert(pos >= 0) src/MSA.cpp:149 */
+    MSQ_ERR_RANGE = -6,    /* std::out_of_range: referenceSequence.substr(absPos,3) src/AminoAcidCaller.cpp:446,
+                              or a factorial argument beyond the reserved log-factorial table */
+    MSQ_ERR_NODEVICE = -7, /* no usable GPU: the product path has no CPU fallback */
+    MSQ_ERR_NOMEM = -8
+};
+
+typedef struct msq_ctx msq_ctx;
+
+const char* msq_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ context */
+int msq_ctx_create(int device, msq_ctx** out);
+int msq_ctx_destroy(msq_ctx* ctx);
+/* hip_stream is a hipStream_t (NULL = the null stream).  The context does not own it. */
+int msq_ctx_set_stream(msq_ctx* ctx, void* hip_stream);
+int msq_ctx_sync(msq_ctx* ctx);
+/* Small device-memory helpers so a C++ host that does not include HIP headers can drive the layer. */
+int msq_dev_malloc(msq_ctx* ctx, size_t bytes, void** d_out);
+int msq_dev_free(msq_ctx* ctx, void* d_ptr);
+int msq_dev_memset(msq_ctx* ctx, void* d_ptr, int value, size_t bytes);           /* async on the stream */
+int msq_memcpy_h2d(msq_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* async on the stream */
+int msq_memcpy_d2h(msq_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronises */
+
+/* ------------------------------------------------------------------------------------- packed read format
+ * Replaces the in-memory type of the path, std::vector<ArrayBase> per ArrayRead
+ * (include/pacbio/data/ArrayRead.h:60-81,96-119; 48 B per base) by 4 bits + 1 QV byte per base
+ * (+3 QV bytes with rich QVs).
+ *
+ * A read is a run of 32-base GROUPS; reads start on a group boundary.  Group g holds four 32-bit planes
+ * bop[4g..4g+3] = {nucleotide bit0, nucleotide bit1, op bit0, op bit1}; bit k of each plane belongs to
+ * base k of the group (genomic order, inserted bases included):
+ *     nucleotide code  A=0 C=1 G=2 T=3                  (NucleotideConversion.h:69-88 order)
+ *     op 0  '=' / 'X'   column-consuming, nucleotide subject to the QV mask   (MSA.cpp:160-167)
+ *     op 1  column-consuming symbol that is not a QV-checked ACGT; the nucleotide code selects it:
+ *           0 = 'D' -> '-' (MSA.cpp:168-171), 1 = a match whose nucleotide is a literal 'N',
+ *           2 = a match whose nucleotide is none of ACGTN- (raises MSQ_ERR_BASE unless QV-masked to 'N'),
+ *           3 = a match whose nucleotide is a literal '-'
+ *     op 2  'I' inserted base, consumes no column (MSA.cpp:172-174)
+ *     op 3  'P' / 'S' / padding after the last base of the read: consumes nothing (MSA.cpp:175-180)
+ * QV planes hold one byte per base, 32 per group; a NULL plane means "QV absent for every base"
+ * (boost::none in ArrayBase, ArrayRead.h:111-114), which always passes (ArrayRead.inl:72-87).
+ */
+typedef struct msq_packed_reads {
+    uint64_t n_reads;
+    uint64_t n_groups;          /* total groups == group_off[n_reads] */
+    const int32_t* ref_start;   /* [n_reads] ArrayRead::ReferenceStart(), 0-based */
+    const int32_t* ref_end;     /* [n_reads] ArrayRead::ReferenceEnd(), exclusive */
+    const uint64_t* group_off;  /* [n_reads+1] first group of each read */
+    const uint32_t* bop;        /* [n_groups*4] */
+    const uint8_t* qual;        /* [n_groups*32] or NULL */
+    const uint8_t* delqv;       /* [n_groups*32] or NULL */
+    const uint8_t* subqv;       /* [n_groups*32] or NULL */
+    const uint8_t* insqv;       /* [n_groups*32] or NULL */
+    uint32_t flags;             /* MSQ_READS_* */
+    uint32_t reserved;
+} msq_packed_reads;
+
+#define MSQ_READS_HAS_EXOTIC 1u /* some base uses op 1 with nucleotide code 2 or 3 */
+
+/* QvThresholds (include/pacbio/data/QvThresholds.h:44-54, src/QvThresholds.cpp:45-56): -1 = boost::none. */
+typedef struct msq_qv_thresholds {
+    int32_t qual, del, sub, ins;
+} msq_qv_thresholds;
+/* QvThresholds::QvThresholds(): environment DELQV, SUBQV (default 42), INSQV, QUALQV.  Host. */
+int msq_qv_thresholds_from_env(msq_qv_thresholds* out);
+
+/* Host packer: flat ArrayBase columns -> packed host buffers owned by the returned object.
+ * Replaces the per-base walk of MSAByRow::AddRead (src/MSA.cpp:144-186) over ArrayRead::Bases().
+ * cigar[i] in "=XDIPS" (anything else: MSQ_ERR_CIGAR), nuc[i] the ArrayBase::Nucleotide char,
+ * qual/subqv/delqv/insqv per-base QVs or NULL, base_off[n_reads+1] prefix offsets into those arrays. */
+typedef struct msq_packed_host msq_packed_host;
+int msq_pack_reads(uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end, const int64_t* base_off,
+                   const char* cigar, const char* nuc, const uint8_t* qual, const uint8_t* subqv,
+                   const uint8_t* delqv, const uint8_t* insqv, msq_packed_host** out);
+const msq_packed_reads* msq_packed_host_view(const msq_packed_host* p);
+int msq_packed_host_free(msq_packed_host* p);
+/* Copy a host-resident packed set to freshly allocated device memory (async H2D on the stream). */
+typedef struct msq_packed_dev msq_packed_dev;
+int msq_reads_upload(msq_ctx* ctx, const msq_packed_reads* host_reads, msq_packed_dev** out);
+const msq_packed_reads* msq_packed_dev_view(const msq_packed_dev* p);
+int msq_packed_dev_free(msq_ctx* ctx, msq_packed_dev* p);
+
+/* ----------------------------------------------------------------------------------------------- pileup
+ * MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:96-97,138-142): begin0 = min ReferenceStart,
+ * end0 = max ReferenceEnd (0-based; MSAByRow::BeginPos()/EndPos() report begin0+1 / end0+1, MSA.cpp:107-108).
+ * No reads: begin0 = INT32_MAX, end0 = 0.  d_reads fields are device pointers.  Synchronises. */
+int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* begin0, int32_t* end0);
+
+/* MSAByRow::MSAByRow + MSAByColumn::MSAByColumn + MSAByRow::CodonsAt for every column
+ * (src/MSA.cpp:55-92, 94-136, 144-219) as two dense count matrices, ADDED into the caller's buffers:
+ *   d_nuc  [W][6]  u32, bins A C G T - N            == MSAColumn::counts_ (MSA.h:194)
+ *   d_codon[W][64] u32, bin 16*b0+4*b1+b2 (A0..T3)  == CodonsAt(c)[codon]; column 0 and columns >= W-2
+ *                  stay zero (MSARow::CodonAt's i > 0 rule and CodingCodonAt's bound, MSA.cpp:193,207).
+ * The caller zeroes the matrices (msq_dev_memset) before the first shard and may call repeatedly to
+ * accumulate shards.  d_reads fields are device pointers.  Async. */
+#define MSQ_PILEUP_AUTO 0     /* pick the kernel */
+#define MSQ_PILEUP_SIMPLE 1   /* force the simple per-read kernel (any width, any op) */
+#define MSQ_PILEUP_STREAM 2   /* force the streaming bit-plane kernel (error if not applicable) */
+int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
+               int32_t W, uint32_t* d_nuc, uint32_t* d_codon, int mode);
+/* Deferred device-side error of the pileups enqueued since the last check (MSQ_ERR_BASE / MSQ_ERR_WINDOW).
+ * Synchronises. */
+int msq_pileup_check(msq_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------ cell testing
+ * A plan fixes which (gene, codon position) pairs AminoAcidCaller::CallVariants visits
+ * (src/AminoAcidCaller.cpp:413-427): for each gene, i = begin; i < end-2; (i-begin)%3==0, 1-based.
+ * n_genes == 0 -> one gene [begin1, end1) ("Unnamed ORF", :402-405).  ref_seq NULL/ref_len 0 -> no
+ * reference (:411).  begin1 = MSAByRow::BeginPos() = win_begin0 + 1.  Host arrays. */
+typedef struct msq_plan msq_plan;
+int msq_plan_create(msq_ctx* ctx, int32_t n_genes, const int32_t* gene_begin, const int32_t* gene_end,
+                    const char* ref_seq, int64_t ref_len, int32_t begin1, int32_t W, msq_plan** out);
+int64_t msq_plan_positions(const msq_plan* plan);
+int msq_plan_destroy(msq_ctx* ctx, msq_plan* plan);
+
+/* Per visited codon position (same field meaning as the locals of CallVariants, :417-463). */
+typedef struct msq_position {
+    int32_t gene;       /* index into the plan's gene list */
+    int32_t i;          /* 1-based reference position of the codon start */
+    int32_t aa_pos;     /* 1 + relPos/3 */
+    int32_t win_pos;    /* i - begin1 */
+    int32_t coverage;   /* sum of the codon counts at win_pos */
+    int32_t ref_codon;  /* refCodon index, -1 if unset / not a codon */
+    int32_t alt_codon;  /* altRefCodon index, -1 if unset (:455-458) */
+    int32_t maj_codon;  /* FindMajorityCodon (:380-395), -1 if none */
+    int32_t maj_count;
+    int32_t skipped;    /* 1 if CallVariants 'continue's before the cell loop */
+} msq_position;
+
+/* ErrorEstimates (include/pacbio/juliet/ErrorEstimates.h:57-60). */
+typedef struct msq_error_model {
+    double match, substitution, deletion;
+} msq_error_model;
+/* ErrorEstimates(chemistry) src/ErrorEstimates.cpp:44-49 / ErrorEstimates(sub, del) :61-67.  Host. */
+int msq_error_model_default(msq_error_model* out);
+int msq_error_model_from_rates(double substitution_rate, double deletion_rate, msq_error_model* out);
+
+/* Reserve the log-factorial table factln(n) = lgamma(n+1.0), n <= max_n (src/Fisher.cpp:115-125), built on
+ * the host with the same libm lgamma the reference calls and kept in HBM by the context.  A table that is
+ * too small for a call makes that call fail with MSQ_ERR_RANGE.  msq_call_cells needs max_n >= 2*coverage+1. */
+int msq_lfact_reserve(msq_ctx* ctx, int64_t max_n);
+
+/* CountNumberOfTests (src/AminoAcidCaller.cpp:86-103) then the per-(position, codon) cell evaluation of
+ * CallVariants (:435-488): coverage, majority/ref/altRef codon, expected = coverage * Probability(ref, codon)
+ * (:325-339), p = fisher_exact_tiss(ceil(cnt), ceil(cov-cnt), ceil(exp), ceil(cov-exp)) * numberOfTests
+ * clipped to 1.  Outputs (device):
+ *   d_positions [P]      msq_position
+ *   d_p         [P][64]  f64; -1.0 where the reference evaluates no cell (count 0, ref/altRef codon, skipped)
+ *   d_expected  [P][64]  f64 expected count (0 where no cell); may be NULL
+ *   d_n_tests   [1]      i32 numberOfTests
+ * Async; device-side failures are reported by msq_call_check. */
+int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t* d_codon, const msq_error_model* err,
+                   double maximal_perc, msq_position* d_positions, double* d_p, double* d_expected,
+                   int32_t* d_n_tests);
+int msq_call_check(msq_ctx* ctx); /* synchronises */
+
+/* Statistics::Fisher::fisher_exact_tiss (include/pacbio/statistics/Fisher.h:15, src/Fisher.cpp:12-77)
+ * evaluated on the GPU for n tables; host arrays in, host array out.  Synchronises. */
+int msq_fisher_batch(msq_ctx* ctx, int64_t n, const int32_t* chi11, const int32_t* chi12, const int32_t* chi21,
+                     const int32_t* chi22, double* p_out);
+int msq_fisher(msq_ctx* ctx, int32_t chi11, int32_t chi12, int32_t chi21, int32_t chi22, double* p_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSQ_ABI_H */

@@ -1,0 +1,152 @@
+"""ctypes binding of include/msq_abi.h and include/msq_synth.h (libmsq_hip.so).
+
+Harness plumbing only (tests, bench.py, smoke): the product is the C-ABI library and the C++ front in
+minorseq_amd/cpp.  There is no CPU fallback: loading fails loudly when the HIP library is missing.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmsq_hip.so")
+
+MSQ_OK = 0
+MSQ_ERR_ARG, MSQ_ERR_HIP, MSQ_ERR_CIGAR, MSQ_ERR_BASE = -1, -2, -3, -4
+MSQ_ERR_WINDOW, MSQ_ERR_RANGE, MSQ_ERR_NODEVICE, MSQ_ERR_NOMEM = -5, -6, -7, -8
+MSQ_PILEUP_AUTO, MSQ_PILEUP_SIMPLE, MSQ_PILEUP_STREAM = 0, 1, 2
+MSQ_READS_HAS_EXOTIC = 1
+
+
+class MsqError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("msq error %d: %s" % (code, text))
+        self.code = code
+
+
+class PackedReads(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_uint64),
+        ("n_groups", C.c_uint64),
+        ("ref_start", C.c_void_p),
+        ("ref_end", C.c_void_p),
+        ("group_off", C.c_void_p),
+        ("bop", C.c_void_p),
+        ("qual", C.c_void_p),
+        ("delqv", C.c_void_p),
+        ("subqv", C.c_void_p),
+        ("insqv", C.c_void_p),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class QvThresholds(C.Structure):
+    _fields_ = [("qual", C.c_int32), ("del_", C.c_int32), ("sub", C.c_int32), ("ins", C.c_int32)]
+
+    @classmethod
+    def make(cls, qual=-1, del_=-1, sub=-1, ins=-1):
+        return cls(qual, del_, sub, ins)
+
+
+class Position(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "gene", "i", "aa_pos", "win_pos", "coverage", "ref_codon", "alt_codon", "maj_codon", "maj_count", "skipped")]
+
+
+class ErrorModel(C.Structure):
+    _fields_ = [("match", C.c_double), ("substitution", C.c_double), ("deletion", C.c_double)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint64),
+        ("win_begin0", C.c_int32),
+        ("W", C.c_int32),
+        ("thr_sub", C.c_uint32),
+        ("thr_del", C.c_uint32),
+        ("thr_ins", C.c_uint32),
+        ("thr_minor", C.c_uint32),
+        ("n_minors", C.c_int32),
+        ("thr_jitter", C.c_uint32),
+        ("max_jitter", C.c_int32),
+        ("rich_qv", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/*.h declares
+_P = C.c_void_p
+_SIGNATURES = {
+    "msq_last_error": (C.c_char_p, []),
+    "msq_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "msq_ctx_destroy": (C.c_int, [_P]),
+    "msq_ctx_set_stream": (C.c_int, [_P, _P]),
+    "msq_ctx_sync": (C.c_int, [_P]),
+    "msq_dev_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "msq_dev_free": (C.c_int, [_P, _P]),
+    "msq_dev_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
+    "msq_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "msq_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "msq_qv_thresholds_from_env": (C.c_int, [C.POINTER(QvThresholds)]),
+    "msq_pack_reads": (C.c_int, [C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P)]),
+    "msq_packed_host_view": (C.POINTER(PackedReads), [_P]),
+    "msq_packed_host_free": (C.c_int, [_P]),
+    "msq_reads_upload": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(_P)]),
+    "msq_packed_dev_view": (C.POINTER(PackedReads), [_P]),
+    "msq_packed_dev_free": (C.c_int, [_P, _P]),
+    "msq_window_bounds": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "msq_pileup": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P, C.c_int]),
+    "msq_pileup_check": (C.c_int, [_P]),
+    "msq_plan_create": (C.c_int, [_P, C.c_int32, _P, _P, C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "msq_plan_positions": (C.c_int64, [_P]),
+    "msq_plan_destroy": (C.c_int, [_P, _P]),
+    "msq_error_model_default": (C.c_int, [C.POINTER(ErrorModel)]),
+    "msq_error_model_from_rates": (C.c_int, [C.c_double, C.c_double, C.POINTER(ErrorModel)]),
+    "msq_lfact_reserve": (C.c_int, [_P, C.c_int64]),
+    "msq_call_cells": (C.c_int, [_P, _P, _P, C.POINTER(ErrorModel), C.c_double, _P, _P, _P, _P]),
+    "msq_call_check": (C.c_int, [_P]),
+    "msq_fisher_batch": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P, _P]),
+    "msq_fisher": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    # include/msq_synth.h
+    "msq_synth_host_lengths": (C.c_int, [C.POINTER(SynthParams), C.c_uint64, C.c_uint64, _P]),
+    "msq_synth_host_fill": (C.c_int, [C.POINTER(SynthParams), _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "msq_synth_dev_group_counts": (C.c_int, [_P, C.POINTER(SynthParams), C.c_uint64, C.c_uint64, _P]),
+    "msq_synth_dev_fill": (C.c_int, [_P, C.POINTER(SynthParams), _P, C.c_uint64, C.POINTER(PackedReads)]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """The loaded libmsq_hip.so.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C minorseq_amd/csrc)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            f = getattr(l, name)  # AttributeError if the library lacks a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != MSQ_OK:
+        raise MsqError(rc, lib().msq_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def ptr(a):
+    """Address of a numpy array / torch tensor / int / None as a void*."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a.ctypes.data

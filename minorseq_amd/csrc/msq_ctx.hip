@@ -1,0 +1,217 @@
+// msq_ctx.hip -- context, error text, device-memory helpers, log-factorial table.
+#include "msq_internal.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void msq_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int msq_fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* msq_last_error(void) { return g_err; }
+
+extern "C" int msq_ctx_create(int device, msq_ctx** out)
+{
+    if (!out) return msq_fail(MSQ_ERR_ARG, "msq_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return msq_fail(MSQ_ERR_NODEVICE, "msq_ctx_create: no HIP device (this layer has no CPU fallback)");
+    if (device < 0 || device >= n) return msq_fail(MSQ_ERR_ARG, "msq_ctx_create: device %d of %d", device, n);
+    MSQ_HIP(hipSetDevice(device));
+    msq_ctx* c = new msq_ctx;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+    hipError_t e = hipMalloc(&c->d_err, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(uint32_t));
+    if (e != hipSuccess) {
+        delete c;
+        return msq_fail(MSQ_ERR_HIP, "msq_ctx_create: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return MSQ_OK;
+}
+
+extern "C" int msq_ctx_destroy(msq_ctx* ctx)
+{
+    if (!ctx) return MSQ_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_err) (void)hipFree(ctx->d_err);
+    if (ctx->d_lfact) (void)hipFree(ctx->d_lfact);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    delete ctx;
+    return MSQ_OK;
+}
+
+extern "C" int msq_ctx_set_stream(msq_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return msq_fail(MSQ_ERR_ARG, "msq_ctx_set_stream: ctx is NULL");
+    ctx->stream = (hipStream_t)hip_stream;
+    return MSQ_OK;
+}
+
+extern "C" int msq_ctx_sync(msq_ctx* ctx)
+{
+    if (!ctx) return msq_fail(MSQ_ERR_ARG, "msq_ctx_sync: ctx is NULL");
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return MSQ_OK;
+}
+
+extern "C" int msq_dev_malloc(msq_ctx* ctx, size_t bytes, void** d_out)
+{
+    if (!ctx || !d_out) return msq_fail(MSQ_ERR_ARG, "msq_dev_malloc: NULL argument");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    *d_out = nullptr;
+    if (bytes == 0) bytes = 4;
+    hipError_t e = hipMalloc(d_out, bytes);
+    if (e != hipSuccess) return msq_fail(MSQ_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return MSQ_OK;
+}
+extern "C" int msq_dev_free(msq_ctx* ctx, void* d_ptr)
+{
+    if (!ctx) return msq_fail(MSQ_ERR_ARG, "msq_dev_free: ctx is NULL");
+    if (d_ptr) {
+        MSQ_HIP(hipStreamSynchronize(ctx->stream));
+        MSQ_HIP(hipFree(d_ptr));
+    }
+    return MSQ_OK;
+}
+extern "C" int msq_dev_memset(msq_ctx* ctx, void* d_ptr, int value, size_t bytes)
+{
+    if (!ctx || (!d_ptr && bytes)) return msq_fail(MSQ_ERR_ARG, "msq_dev_memset: NULL argument");
+    if (bytes) MSQ_HIP(hipMemsetAsync(d_ptr, value, bytes, ctx->stream));
+    return MSQ_OK;
+}
+extern "C" int msq_memcpy_h2d(msq_ctx* ctx, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!ctx || ((!d_dst || !h_src) && bytes)) return msq_fail(MSQ_ERR_ARG, "msq_memcpy_h2d: NULL argument");
+    if (bytes) MSQ_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MSQ_OK;
+}
+extern "C" int msq_memcpy_d2h(msq_ctx* ctx, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx || ((!h_dst || !d_src) && bytes)) return msq_fail(MSQ_ERR_ARG, "msq_memcpy_d2h: NULL argument");
+    if (bytes) MSQ_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return MSQ_OK;
+}
+
+int msq_scratch(msq_ctx* ctx, size_t bytes, void** out)
+{
+    if (bytes > ctx->scratch_bytes) {
+        MSQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_scratch) MSQ_HIP(hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = bytes + (bytes >> 2) + 4096;
+        hipError_t e = hipMalloc(&ctx->d_scratch, want);
+        if (e != hipSuccess) return msq_fail(MSQ_ERR_NOMEM, "scratch hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->d_scratch;
+    return MSQ_OK;
+}
+
+// QvThresholds::QvThresholds(), src/QvThresholds.cpp:45-56: getenv + std::stoi, SUBQV defaults to 42.
+extern "C" int msq_qv_thresholds_from_env(msq_qv_thresholds* out)
+{
+    if (!out) return msq_fail(MSQ_ERR_ARG, "msq_qv_thresholds_from_env: out is NULL");
+    auto get = [](const char* name, int dflt, int32_t* dst) -> int {
+        const char* v = std::getenv(name);
+        if (!v) {
+            *dst = dflt;
+            return MSQ_OK;
+        }
+        try {
+            // boost::optional<uint8_t> = std::stoi(...): the int narrows to uint8_t
+            *dst = (int32_t)(uint8_t)std::stoi(std::string(v));
+        } catch (const std::exception& e) {
+            return msq_fail(MSQ_ERR_ARG, "%s: std::stoi failed on '%s'", name, v);
+        }
+        return MSQ_OK;
+    };
+    int rc;
+    if ((rc = get("DELQV", -1, &out->del)) != MSQ_OK) return rc;
+    if ((rc = get("SUBQV", 42, &out->sub)) != MSQ_OK) return rc;
+    if ((rc = get("INSQV", -1, &out->ins)) != MSQ_OK) return rc;
+    if ((rc = get("QUALQV", -1, &out->qual)) != MSQ_OK) return rc;
+    return MSQ_OK;
+}
+
+// ErrorEstimates(chemistry), src/ErrorEstimates.cpp:44-49 (same numbers for every chemistry).
+extern "C" int msq_error_model_default(msq_error_model* out)
+{
+    if (!out) return msq_fail(MSQ_ERR_ARG, "msq_error_model_default: out is NULL");
+    out->match = 0.9956844883;
+    out->substitution = 0.0005244257 / 3.0;
+    out->deletion = 0.003791086;
+    return MSQ_OK;
+}
+// ErrorEstimates(substitutionRate, deletionRate), src/ErrorEstimates.cpp:61-67.
+extern "C" int msq_error_model_from_rates(double substitution_rate, double deletion_rate, msq_error_model* out)
+{
+    if (!out) return msq_fail(MSQ_ERR_ARG, "msq_error_model_from_rates: out is NULL");
+    out->match = 1 - substitution_rate - deletion_rate;
+    out->substitution = substitution_rate / 3.0;
+    out->deletion = deletion_rate;
+    return MSQ_OK;
+}
+
+// factln table, src/Fisher.cpp:115-125: 0 for n <= 1, else lgamma(n + 1.0) from the host libm (the very
+// function the reference calls, so the values are bit-identical to the reference's on the same host).
+extern "C" int msq_lfact_reserve(msq_ctx* ctx, int64_t max_n)
+{
+    if (!ctx || max_n < 0) return msq_fail(MSQ_ERR_ARG, "msq_lfact_reserve: bad argument");
+    if (max_n <= ctx->lfact_n) return MSQ_OK;
+    if (max_n < 4096) max_n = 4096;
+    MSQ_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)max_n + 1;
+    std::vector<double> tab(n);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 16) nt = 16;
+    if (n < 1u << 16) nt = 1;
+    auto fill = [&tab](size_t lo, size_t hi) {
+        int sign;
+        for (size_t i = lo; i < hi; ++i) tab[i] = i <= 1 ? 0.0 : lgamma_r((double)((int)i + 1.0), &sign);
+    };
+    if (nt == 1) {
+        fill(0, n);
+    } else {
+        std::vector<std::thread> th;
+        const size_t per = (n + nt - 1) / nt;
+        for (unsigned t = 0; t < nt; ++t) {
+            const size_t lo = t * per, hi = lo + per < n ? lo + per : n;
+            if (lo < hi) th.emplace_back(fill, lo, hi);
+        }
+        for (auto& t : th) t.join();
+    }
+    double* d = nullptr;
+    hipError_t e = hipMalloc(&d, n * sizeof(double));
+    if (e != hipSuccess) return msq_fail(MSQ_ERR_NOMEM, "lfact hipMalloc(%zu): %s", n * sizeof(double), hipGetErrorString(e));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    MSQ_HIP(hipMemcpy(d, tab.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    if (ctx->d_lfact) MSQ_HIP(hipFree(ctx->d_lfact));
+    ctx->d_lfact = d;
+    ctx->lfact_n = max_n;
+    return MSQ_OK;
+}

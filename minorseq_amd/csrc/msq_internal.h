@@ -1,0 +1,43 @@
+// msq_internal.h -- shared by the translation units of libmsq_hip.so (not part of the ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/msq_abi.h"
+
+// Symbol codes of one MSA cell as the kernels see it (MSARow::Bases chars, include/pacbio/data/MSA.h:99-101).
+// 1..6 minus one is the NucleotideToTag order A C G T - N (NucleotideConversion.h:69-88).
+enum : int { SYM_BLANK = 0, SYM_A = 1, SYM_C = 2, SYM_G = 3, SYM_T = 4, SYM_GAP = 5, SYM_N = 6 };
+
+// Device-side deferred error word (bit set): reported by msq_pileup_check / msq_call_check.
+enum : uint32_t { DEVERR_BASE = 1u, DEVERR_WINDOW = 2u, DEVERR_RANGE = 4u };
+
+struct msq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* d_err = nullptr;      // [1] deferred error bits
+    double* d_lfact = nullptr;      // [lfact_n + 1] lgamma(n + 1.0)
+    int64_t lfact_n = -1;
+    int n_cu = 256;
+    // scratch owned by the context, grown on demand
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+};
+
+void msq_set_error(const char* fmt, ...);
+int msq_fail(int code, const char* fmt, ...);
+
+#define MSQ_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return msq_fail(MSQ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                            __LINE__);                                                                  \
+    } while (0)
+
+int msq_scratch(msq_ctx* ctx, size_t bytes, void** out);

@@ -1,0 +1,219 @@
+// msq_pileup.hip -- window bounds + the SIMPLE pileup kernel (one wave per read, byte rows in LDS).
+//
+// The simple kernel is the obviously-correct device restatement of MSAByRow::AddRead + MSAByColumn +
+// CodonsAt (src/MSA.cpp:55-92,126-136,144-219): it handles any window width that fits one LDS row and
+// every op of the packed format.  The streaming bit-plane kernel (msq_pileup_stream.hip) is the fast
+// path; msq_pileup() picks between them.
+#include "msq_internal.h"
+
+#include <climits>
+
+int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr,
+                             int32_t win_begin0, int32_t W, uint32_t* d_nuc, uint32_t* d_codon, bool* handled);
+
+// ------------------------------------------------------------------------------------------ window bounds
+__global__ void window_bounds_kernel(const int32_t* __restrict__ ref_start, const int32_t* __restrict__ ref_end,
+                                     uint64_t n, int32_t* __restrict__ out /* {min start, max end} */)
+{
+    int32_t lo = INT_MAX, hi = 0;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        lo = min(lo, ref_start[i]);
+        hi = max(hi, ref_end[i]);
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d));
+        hi = max(hi, __shfl_xor(hi, d));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out[0], lo);
+        atomicMax(&out[1], hi);
+    }
+}
+
+extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* begin0, int32_t* end0)
+{
+    if (!ctx || !d_reads || !begin0 || !end0) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds: NULL argument");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    void* s = nullptr;
+    int rc = msq_scratch(ctx, 64, &s);
+    if (rc != MSQ_OK) return rc;
+    int32_t init[2] = {INT_MAX, 0};
+    MSQ_HIP(hipMemcpyAsync(s, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    if (d_reads->n_reads) {
+        if (!d_reads->ref_start || !d_reads->ref_end) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds: NULL ref arrays");
+        uint64_t blocks = (d_reads->n_reads + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_reads->ref_start,
+                           d_reads->ref_end, d_reads->n_reads, (int32_t*)s);
+        MSQ_HIP(hipGetLastError());
+    }
+    int32_t res[2];
+    MSQ_HIP(hipMemcpyAsync(res, s, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    *begin0 = res[0];
+    *end0 = res[1];
+    return MSQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------ simple kernel
+struct QvPlanes {
+    const uint8_t* plane[4];  // qual, del, sub, ins
+    int32_t thr[4];           // -1 = unset
+};
+
+// ArrayBase::MeetQVThresholds (include/pacbio/data/internal/ArrayRead.inl:67-87)
+__device__ __forceinline__ bool meets_qv(const QvPlanes& q, uint64_t base_index)
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (q.thr[k] >= 0 && q.plane[k]) ok = ok && (q.plane[k][base_index] >= (uint8_t)q.thr[k]);
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void pileup_simple_kernel(
+    const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ group_off, const uint4* __restrict__ bop,
+    QvPlanes qv, uint64_t n_reads, int32_t win_begin0, int32_t W, int32_t row_bytes, int32_t waves_per_wg,
+    uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon, uint32_t* __restrict__ err)
+{
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t* row = lds + (size_t)wave * row_bytes;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_wg;
+    const uint64_t iters = (n_reads + total_waves - 1) / total_waves;
+    uint32_t my_err = 0;
+
+    for (uint64_t it = 0; it < iters; ++it) {
+        const uint64_t r = it * total_waves + (uint64_t)blockIdx.x * waves_per_wg + wave;
+        const bool active = r < n_reads;
+        for (int c = lane * 4; c < row_bytes; c += 256) *reinterpret_cast<uint32_t*>(row + c) = 0;  // MSARow(size): ' '
+        __syncthreads();
+        if (active) {
+            const uint64_t g0 = group_off[r], g1 = group_off[r + 1];
+            int col = ref_start[r] - win_begin0;  // MSA.cpp:148
+            for (uint64_t gb = g0; gb < g1; gb += 64) {
+                const uint64_t g = gb + lane;
+                uint4 w = make_uint4(0u, 0u, ~0u, ~0u);  // beyond the read: op 3
+                if (g < g1) w = bop[g];
+                const uint32_t cons = ~w.w;  // ops 0 and 1 consume a column
+                const int n = __popc(cons);
+                int incl = n;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(incl, d);
+                    if (lane >= d) incl += t;
+                }
+                int c = col + incl - n;
+                const int total = __shfl(incl, 63);
+                for (int k = 0; k < 32; ++k) {
+                    const uint32_t op = ((w.z >> k) & 1u) | (((w.w >> k) & 1u) << 1);
+                    if (op >= 2) continue;  // 'I' (MSA.cpp:172-174), 'P'/'S'/padding (:175-180)
+                    const uint32_t code = ((w.x >> k) & 1u) | (((w.y >> k) & 1u) << 1);
+                    int sym;
+                    if (op == 0) {
+                        sym = meets_qv(qv, g * 32 + k) ? (int)(SYM_A + code) : (int)SYM_N;  // MSA.cpp:163-166
+                    } else if (code == 0) {
+                        sym = SYM_GAP;  // 'D', MSA.cpp:168-171
+                    } else if (code == 1) {
+                        sym = SYM_N;  // literal 'N' nucleotide: 'N' whether or not the QV passes
+                    } else {
+                        const bool ok = meets_qv(qv, g * 32 + k);
+                        if (code == 2) {
+                            if (ok) my_err |= DEVERR_BASE;  // "Unexpected base", MSA.cpp:85
+                            sym = SYM_N;
+                        } else {
+                            sym = ok ? (int)SYM_GAP : (int)SYM_N;  // literal '-' nucleotide at a match
+                        }
+                    }
+                    if (c < 0 || c >= W)
+                        my_err |= DEVERR_WINDOW;
+                    else
+                        row[c] = (uint8_t)sym;
+                    ++c;
+                }
+                col += total;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            for (int c = lane; c < W; c += 64) {
+                const int s0 = row[c];
+                if (s0 == SYM_BLANK) continue;                  // MSA.cpp:81-83
+                atomicAdd(&nuc[(size_t)c * 6 + (s0 - 1)], 1u);  // MSAColumn::IncCounts, MSA.inl:66
+                // CodingCodonAt (MSA.cpp:197-219) + CodonAt's i > 0 rule (:193)
+                if (c >= 1 && c + 2 < W) {
+                    const int s1 = row[c + 1], s2 = row[c + 2];
+                    if (s0 <= SYM_T && s1 >= SYM_A && s1 <= SYM_T && s2 >= SYM_A && s2 <= SYM_T)
+                        atomicAdd(&codon[(size_t)c * 64 + ((s0 - 1) << 4 | (s1 - 1) << 2 | (s2 - 1))], 1u);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (my_err) atomicOr(err, my_err);
+}
+
+static int launch_simple(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
+                         int32_t W, uint32_t* d_nuc, uint32_t* d_codon)
+{
+    const int32_t row_bytes = ((W + 2 + 15) / 16) * 16;
+    int waves = 150 * 1024 / row_bytes;
+    if (waves < 1) return msq_fail(MSQ_ERR_ARG, "msq_pileup: window of %d columns exceeds the simple kernel's LDS row", W);
+    if (waves > 4) waves = 4;
+    const size_t lds = (size_t)row_bytes * waves;
+    if (lds > 48 * 1024)
+        MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pileup_simple_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint64_t blocks = (R.n_reads + waves - 1) / waves;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    QvPlanes q;
+    q.plane[0] = R.qual; q.plane[1] = R.delqv; q.plane[2] = R.subqv; q.plane[3] = R.insqv;
+    q.thr[0] = thr.qual; q.thr[1] = thr.del; q.thr[2] = thr.sub; q.thr[3] = thr.ins;
+    hipLaunchKernelGGL(pileup_simple_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, ctx->stream, R.ref_start,
+                       R.group_off, reinterpret_cast<const uint4*>(R.bop), q, R.n_reads, win_begin0, W, row_bytes,
+                       waves, d_nuc, d_codon, ctx->d_err);
+    MSQ_HIP(hipGetLastError());
+    return MSQ_OK;
+}
+
+extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,
+                          int32_t win_begin0, int32_t W, uint32_t* d_nuc, uint32_t* d_codon, int mode)
+{
+    if (!ctx || !d_reads || !thr) return msq_fail(MSQ_ERR_ARG, "msq_pileup: NULL argument");
+    if (W < 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup: negative window width %d", W);
+    if (d_reads->n_reads == 0 || W == 0) return MSQ_OK;
+    if (!d_nuc || !d_codon) return msq_fail(MSQ_ERR_ARG, "msq_pileup: NULL count matrix");
+    if (!d_reads->ref_start || !d_reads->group_off || !d_reads->bop) return msq_fail(MSQ_ERR_ARG, "msq_pileup: NULL read arrays");
+    if (((uintptr_t)d_reads->bop & 15u) != 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup: bop must be 16-byte aligned");
+    for (int k = 0; k < 4; ++k) {
+        const int32_t t = (&thr->qual)[k];
+        if (t < -1 || t > 255) return msq_fail(MSQ_ERR_ARG, "msq_pileup: QV threshold %d out of range", t);
+    }
+    MSQ_HIP(hipSetDevice(ctx->device));
+    if (mode != MSQ_PILEUP_SIMPLE) {
+        bool handled = false;
+        int rc = msq_pileup_stream_launch(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon, &handled);
+        if (rc != MSQ_OK) return rc;
+        if (handled) return MSQ_OK;
+        if (mode == MSQ_PILEUP_STREAM)
+            return msq_fail(MSQ_ERR_ARG, "msq_pileup: streaming kernel not applicable (W=%d, flags=%u)", W, d_reads->flags);
+    }
+    return launch_simple(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon);
+}
+
+extern "C" int msq_pileup_check(msq_ctx* ctx)
+{
+    if (!ctx) return msq_fail(MSQ_ERR_ARG, "msq_pileup_check: ctx is NULL");
+    uint32_t e = 0;
+    MSQ_HIP(hipMemcpyAsync(&e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    if (e & (DEVERR_BASE | DEVERR_WINDOW)) {
+        const uint32_t keep = e & ~(DEVERR_BASE | DEVERR_WINDOW);
+        MSQ_HIP(hipMemcpyAsync(ctx->d_err, &keep, sizeof(keep), hipMemcpyHostToDevice, ctx->stream));
+        MSQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (e & DEVERR_WINDOW) return msq_fail(MSQ_ERR_WINDOW, "a read reaches outside the MSA window");
+        return msq_fail(MSQ_ERR_BASE, "Unexpected base");
+    }
+    return MSQ_OK;
+}

@@ -1,0 +1,241 @@
+"""Harness-side driver of the C ABI with torch as the device allocator (tests, bench.py, smoke()).
+
+torch is plumbing here (HBM allocation, streams, torch.distributed for the count all-reduce); every
+computation goes through libmsq_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+
+
+class Ctx:
+    def __init__(self, device=0):
+        self.device = device
+        self._h = C.c_void_p()
+        abi.check(abi.lib().msq_ctx_create(device, C.byref(self._h)))
+        self.use_current_stream()
+
+    def use_current_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        abi.check(abi.lib().msq_ctx_set_stream(self._h, s))
+
+    @property
+    def h(self):
+        return self._h
+
+    def sync(self):
+        abi.check(abi.lib().msq_ctx_sync(self._h))
+
+    def lfact_reserve(self, max_n):
+        abi.check(abi.lib().msq_lfact_reserve(self._h, int(max_n)))
+
+    def close(self):
+        if self._h:
+            abi.lib().msq_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _view(addr, dtype, n):
+    if not addr or n == 0:
+        return None
+    buf = (C.c_uint8 * (n * np.dtype(dtype).itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+def pack_host(reads):
+    """msq_pack_reads on unpacked reads (dict as synth.Workload.host_reads returns) -> dict of numpy arrays."""
+    L = abi.lib()
+    h = C.c_void_p()
+    abi.check(L.msq_pack_reads(reads["n_reads"], abi.ptr(reads["ref_start"]), abi.ptr(reads["ref_end"]),
+                               abi.ptr(reads["base_off"]), abi.ptr(reads["cigar"]), abi.ptr(reads["nuc"]),
+                               abi.ptr(reads.get("qual")), abi.ptr(reads.get("subqv")), abi.ptr(reads.get("delqv")),
+                               abi.ptr(reads.get("insqv")), C.byref(h)))
+    try:
+        v = L.msq_packed_host_view(h).contents
+        n, g = int(v.n_reads), int(v.n_groups)
+        out = {
+            "n_reads": n,
+            "n_groups": g,
+            "ref_start": _view(v.ref_start, np.int32, n) if n else np.zeros(0, np.int32),
+            "ref_end": _view(v.ref_end, np.int32, n) if n else np.zeros(0, np.int32),
+            "group_off": _view(v.group_off, np.uint64, n + 1),
+            "bop": _view(v.bop, np.uint32, g * 4) if g else np.zeros(0, np.uint32),
+            "qual": _view(v.qual, np.uint8, g * 32),
+            "delqv": _view(v.delqv, np.uint8, g * 32),
+            "subqv": _view(v.subqv, np.uint8, g * 32),
+            "insqv": _view(v.insqv, np.uint8, g * 32),
+            "flags": int(v.flags),
+        }
+    finally:
+        L.msq_packed_host_free(h)
+    return out
+
+
+class DeviceReads:
+    """Packed reads resident in HBM (torch tensors own the memory) + the msq_packed_reads view of them."""
+
+    FIELDS = ("ref_start", "ref_end", "group_off", "bop", "qual", "delqv", "subqv", "insqv")
+
+    def __init__(self, n_reads, n_groups, tensors, flags=0):
+        self.n_reads, self.n_groups, self.t, self.flags = int(n_reads), int(n_groups), tensors, int(flags)
+        self.view = abi.PackedReads(self.n_reads, self.n_groups,
+                                    *[abi.ptr(tensors.get(f)) for f in self.FIELDS], self.flags, 0)
+
+    def n_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.t.values() if t is not None)
+
+
+def upload(packed, device=0):
+    dev = torch.device("cuda", device)
+    t = {}
+    for f in DeviceReads.FIELDS:
+        a = packed.get(f)
+        if a is None:
+            t[f] = None
+            continue
+        if a.dtype == np.uint64:
+            a = a.view(np.int64)
+        elif a.dtype == np.uint32:
+            a = a.view(np.int32)
+        if a.size == 0:
+            a = np.zeros(4, dtype=a.dtype)
+        t[f] = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return DeviceReads(packed["n_reads"], packed["n_groups"], t, packed.get("flags", 0))
+
+
+def download(dr):
+    """DeviceReads -> dict of numpy arrays in the pack_host() layout."""
+    out = {"n_reads": dr.n_reads, "n_groups": dr.n_groups, "flags": dr.flags}
+    n, g = dr.n_reads, dr.n_groups
+    sizes = {"ref_start": n, "ref_end": n, "group_off": n + 1, "bop": 4 * g, "qual": 32 * g, "delqv": 32 * g,
+             "subqv": 32 * g, "insqv": 32 * g}
+    for f in DeviceReads.FIELDS:
+        t = dr.t.get(f)
+        if t is None:
+            out[f] = None
+            continue
+        a = t.cpu().numpy()[:sizes[f]]
+        if f == "group_off":
+            a = a.view(np.uint64)
+        elif f == "bop":
+            a = a.view(np.uint32)
+        out[f] = a
+    return out
+
+
+def synth_device(ctx, wl, first=0, n=None):
+    """Generate reads [first, first+n) of a synth.Workload directly in HBM (packed)."""
+    n = wl.n_reads - first if n is None else n
+    L = abi.lib()
+    dev = torch.device("cuda", ctx.device)
+    clones = torch.from_numpy(wl.clone_codes).to(dev)
+    ng = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    abi.check(L.msq_synth_dev_group_counts(ctx.h, wl.params, first, n, ng.data_ptr()))
+    group_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    if n:
+        group_off[1:] = torch.cumsum(ng[:n].to(torch.int64), 0)
+    g = int(group_off[-1].item())
+    t = {
+        "ref_start": torch.zeros(max(n, 1), dtype=torch.int32, device=dev),
+        "ref_end": torch.zeros(max(n, 1), dtype=torch.int32, device=dev),
+        "group_off": group_off,
+        "bop": torch.zeros(max(4 * g, 4), dtype=torch.int32, device=dev),
+        "qual": torch.zeros(max(32 * g, 32), dtype=torch.uint8, device=dev),
+        "delqv": torch.zeros(max(32 * g, 32), dtype=torch.uint8, device=dev) if wl.rich_qv else None,
+        "subqv": torch.zeros(max(32 * g, 32), dtype=torch.uint8, device=dev) if wl.rich_qv else None,
+        "insqv": torch.zeros(max(32 * g, 32), dtype=torch.uint8, device=dev) if wl.rich_qv else None,
+    }
+    dr = DeviceReads(n, g, t)
+    abi.check(L.msq_synth_dev_fill(ctx.h, wl.params, clones.data_ptr(), first, dr.view))
+    ctx.sync()
+    return dr
+
+
+def window_bounds(ctx, dr):
+    b, e = C.c_int32(), C.c_int32()
+    abi.check(abi.lib().msq_window_bounds(ctx.h, dr.view, C.byref(b), C.byref(e)))
+    return b.value, e.value
+
+
+def alloc_counts(ctx, W):
+    dev = torch.device("cuda", ctx.device)
+    return (torch.zeros(max(W, 1) * 6, dtype=torch.int32, device=dev),
+            torch.zeros(max(W, 1) * 64, dtype=torch.int32, device=dev))
+
+
+def pileup(ctx, dr, thr, win_begin0, W, nuc=None, codon=None, mode=abi.MSQ_PILEUP_AUTO, check=True):
+    """msq_pileup into (new or given) count matrices; returns (nuc [W,6], codon [W,64]) int32 tensors."""
+    if nuc is None:
+        nuc, codon = alloc_counts(ctx, W)
+    abi.check(abi.lib().msq_pileup(ctx.h, dr.view, thr, win_begin0, W, nuc.data_ptr(), codon.data_ptr(), mode))
+    if check:
+        abi.check(abi.lib().msq_pileup_check(ctx.h))
+    return nuc, codon
+
+
+class Plan:
+    def __init__(self, ctx, gene_begin, gene_end, ref_seq, begin1, W):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        gb = np.ascontiguousarray(gene_begin, dtype=np.int32)
+        ge = np.ascontiguousarray(gene_end, dtype=np.int32)
+        ref = ref_seq.encode() if isinstance(ref_seq, str) else ref_seq
+        abi.check(abi.lib().msq_plan_create(ctx.h, len(gb), abi.ptr(gb) if len(gb) else None,
+                                            abi.ptr(ge) if len(ge) else None, ref, len(ref) if ref else 0, begin1, W,
+                                            C.byref(self._h)))
+        self.P = int(abi.lib().msq_plan_positions(self._h))
+        dev = torch.device("cuda", ctx.device)
+        self.positions = torch.zeros(max(self.P, 1) * 10, dtype=torch.int32, device=dev)
+        self.p = torch.zeros(max(self.P, 1) * 64, dtype=torch.float64, device=dev)
+        self.expected = torch.zeros(max(self.P, 1) * 64, dtype=torch.float64, device=dev)
+        self.n_tests = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    @property
+    def h(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            abi.lib().msq_plan_destroy(self.ctx.h, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def call_cells(ctx, plan, codon, err=None, maximal_perc=100.0, check=True):
+    """msq_call_cells into the plan's output buffers (async unless check)."""
+    if err is None:
+        err = abi.ErrorModel()
+        abi.check(abi.lib().msq_error_model_default(C.byref(err)))
+    abi.check(abi.lib().msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(err), float(maximal_perc),
+                                       plan.positions.data_ptr(), plan.p.data_ptr(), plan.expected.data_ptr(),
+                                       plan.n_tests.data_ptr()))
+    if check:
+        abi.check(abi.lib().msq_call_check(ctx.h))
+
+
+def results(plan):
+    """Host copies: positions [P,10] int32, p [P,64], expected [P,64], n_tests."""
+    P = plan.P
+    return (plan.positions.cpu().numpy()[:P * 10].reshape(P, 10), plan.p.cpu().numpy()[:P * 64].reshape(P, 64),
+            plan.expected.cpu().numpy()[:P * 64].reshape(P, 64), int(plan.n_tests.item()))
+
+
+def fisher_batch(ctx, a, b, c, d):
+    a, b, c, d = (np.ascontiguousarray(x, dtype=np.int32) for x in (a, b, c, d))
+    p = np.zeros(len(a), dtype=np.float64)
+    abi.check(abi.lib().msq_fisher_batch(ctx.h, len(a), abi.ptr(a), abi.ptr(b), abi.ptr(c), abi.ptr(d), abi.ptr(p)))
+    return p

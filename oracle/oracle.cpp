@@ -1,0 +1,505 @@
+// oracle.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of juliet's pileup + Fisher hot path (PacBio MinorSeq 1.10.0).  It exists so the HIP
+// path can be checked; it is never linked, imported or called by the product (minorseq_amd/).  Only
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+//
+// Pinning status (also in DESIGN.md):
+//   * Fisher (orc_fisher):   PINNED  -- reference KAT tests/unit/FisherTest.cpp:53-73 and the reference's
+//                            own Fisher.cpp compiled unmodified into oracle/_ref (Makefile target ref).
+//   * codon table / priors / tag order: PINNED against the reference's AminoAcidTable.cpp,
+//                            ErrorEstimates.cpp, NucleotideConversion.cpp compiled into oracle/_ref.
+//   * pileup + cell loop (orc_msa_*, orc_call): PARITY UNPINNED -- the reference holds no test, fixture or
+//                            golden vector for MSA / AminoAcidCaller, and MSA.cpp /
+//                            AminoAcidCaller.cpp need boost + pbbam + pbcopper headers that this image
+//                            lacks, so they are unbuildable here.  The restatement follows the reference
+//                            source line by line in behaviour (citations below) and is cross-checked by
+//                            an independent literal Python model (oracle/pymodel.py).
+//
+// All reference citations are relative to /root/reference/.
+//
+// Data model: reads arrive as flat "ArrayBase" columns (include/pacbio/data/ArrayRead.h:96-119):
+//   cigar[]  one of '=' 'X' 'D' 'I' 'P' 'S' per base, nuc[] the nucleotide char, qual/sub/del/ins QVs
+//   (NULL pointer == boost::none for every base), base_off[n+1] prefix offsets, ref_start/ref_end 0-based.
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------- Fisher (src/Fisher.cpp:12-143)
+// factln: src/Fisher.cpp:115-125.  The reference caches n<=100 in a static array; the cached value is the
+// same lgamma(n+1.0) so the cache is not restated.
+double factln(int n)
+{
+    if (n <= 1) return 0.0;
+    return lgamma((double)(n + 1.0));
+}
+// binomialln: src/Fisher.cpp:127 (association order (f(n)-f(k))-f(n-k) matters for rounding)
+double binomialln(int n, int k) { return (factln(n) - factln(k) - factln(n - k)); }
+// calc_hypergeom: src/Fisher.cpp:129-143
+double hypergeom(int a, int b, int c, int d)
+{
+    const int total = a + b + c + d;
+    const double b1 = binomialln(a + b, a);
+    const double b2 = binomialln(c + d, c);
+    const double b3 = binomialln(total, a + c);
+    return exp(b1 + b2 - b3);
+}
+// factorInc / factorDec: src/Fisher.cpp:79-92
+double factor_inc(int a, int b, int c, int d)
+{
+    double f = (double)b * c;
+    f /= (double)(a + 1) * (d + 1);
+    return f;
+}
+double factor_dec(int a, int b, int c, int d)
+{
+    double f = (double)a * d;
+    f /= (double)(c + 1) * (b + 1);
+    return f;
+}
+// fisher_exact_tiss: src/Fisher.cpp:12-77.  One-sided "greater"; edge of the table -> point probability
+// only (:42); factor_inc >= factor_dec -> 1.0 (:71-74).
+double fisher_tiss(int a, int b, int c, int d)
+{
+    int co = a;
+    const int ga = a + b, gb = a + c, total = a + b + c + d;
+    int min_co = 0;
+    if (ga + gb > total) min_co = ga + gb - total;
+    const int max_co = ga < gb ? ga : gb;
+    double base_p = hypergeom(a, b, c, d);
+    if (!(co == max_co || co == min_co)) {
+        double fi = factor_inc(a, b, c, d);
+        const double fd = factor_dec(a, b, c, d);
+        double curr = base_p;
+        if (fi < fd) {
+            do {
+                curr *= fi;
+                base_p += curr;
+                co++;
+                a++; d++; b--; c--;
+                fi = factor_inc(a, b, c, d);
+            } while (co < max_co);
+        } else {
+            base_p = 1.0;
+        }
+    }
+    return base_p;
+}
+
+// ---------------------------------------------------------------- codon helpers
+// include/pacbio/data/NucleotideConversion.h:69-88: A0 C1 G2 T3 -4 N5
+int nuc_tag(char c)
+{
+    switch (c) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        case '-': return 4;
+        case 'N': return 5;
+        default: return 255;
+    }
+}
+const char kTagChar[6] = {'A', 'C', 'G', 'T', '-', 'N'};
+
+// src/AminoAcidTable.cpp:43-54 holds the standard genetic code with stop -> 'X' for the 64 ACGT codons.
+// Restated from the canonical TCAG-ordered code string; checked against the compiled reference table.
+char amino_acid(int codon_idx /* 16*b0+4*b1+b2, A0 C1 G2 T3 */)
+{
+    static const char* tcag = "FFLLSSSSYYXXCCXWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+    static const int to_tcag[4] = {2, 1, 3, 0};  // A->2 C->1 G->3 T->0 in TCAG order
+    const int b0 = (codon_idx >> 4) & 3, b1 = (codon_idx >> 2) & 3, b2 = codon_idx & 3;
+    return tcag[16 * to_tcag[b0] + 4 * to_tcag[b1] + to_tcag[b2]];
+}
+int codon_index(const std::string& s)  // -1 when not in AminoAcidTable::FromCodon (not 3x ACGT)
+{
+    if (s.size() != 3) return -1;
+    int idx = 0;
+    for (char c : s) {
+        const int t = nuc_tag(c);
+        if (t > 3) return -1;
+        idx = idx * 4 + t;
+    }
+    return idx;
+}
+// ---------------------------------------------------------------- MSA (src/MSA.cpp)
+struct Row
+{
+    std::vector<char> bases;            // include/pacbio/data/MSA.h:99-101
+    std::map<int, std::string> ins;     // MSA.h:103
+};
+
+struct Msa
+{
+    int begin0 = INT_MAX;  // min ReferenceStart, 0-based (MSA.cpp:138-142)
+    int end0 = 0;
+    int W = 0;
+    std::vector<Row> rows;
+    std::vector<int32_t> nuc;                            // [W][6]  MSAByColumn counts (MSA.cpp:55-92)
+    std::vector<std::map<std::string, int>> col_ins;     // per column insertion histogram (MSA.inl:101)
+    int error = 0;
+};
+
+struct Thresholds
+{
+    int qual, del, sub, ins;  // -1 == boost::none (src/QvThresholds.cpp:45-56)
+};
+
+// ArrayBase::MeetQVThresholds, include/pacbio/data/internal/ArrayRead.inl:67-87:
+// pass iff threshold unset OR QV unset OR qv >= threshold, for each of the four.
+inline bool meets(int thr, const uint8_t* qv, size_t i) { return thr < 0 || !qv || qv[i] >= (uint8_t)thr; }
+
+// MSARow::CodonAt, MSA.cpp:188-195 -- note i > 0: index 0 is never appended.
+std::string codon_at(const Row& r, int pos)
+{
+    const int length = (int)r.bases.size();
+    std::string codon;
+    for (int i = pos; i < pos + 3; ++i)
+        if (i > 0 && i < length) codon += r.bases[i];
+    return codon;
+}
+// MSARow::CodingCodonAt, MSA.cpp:197-219
+bool coding_codon_at(const Row& r, int winPos, std::string* codon)
+{
+    if (winPos + 2 >= (int)r.bases.size() || winPos < 0) return false;
+    const char a = r.bases[winPos], b = r.bases[winPos + 1], c = r.bases[winPos + 2];
+    if (a == ' ' || b == ' ' || c == ' ') return false;
+    if (a == '-' || b == '-' || c == '-') return false;
+    const std::string proposed = codon_at(r, winPos);
+    if (codon_index(proposed) < 0) return false;
+    *codon = proposed;
+    return true;
+}
+// MSAByRow::CodonsAt, MSA.cpp:126-136
+std::map<std::string, int> codons_at(const Msa& m, int i)
+{
+    std::map<std::string, int> codons;
+    std::string codon;
+    for (const auto& row : m.rows)
+        if (coding_codon_at(row, i, &codon)) ++codons[codon];
+    return codons;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Error codes mirror the reference's exceptions.
+enum { ORC_OK = 0, ORC_BAD_CIGAR = -1, ORC_OUT_OF_WINDOW = -2, ORC_BAD_BASE = -3, ORC_BAD_ARG = -4 };
+
+double orc_fisher(int a, int b, int c, int d) { return fisher_tiss(a, b, c, d); }
+
+char orc_amino_acid(int codon_idx) { return amino_acid(codon_idx & 63); }
+
+// ErrorEstimates(chemistry), src/ErrorEstimates.cpp:44-49, and (sub, del), :61-67.  out = {Match, Substitution, Deletion, Insertion}
+void orc_error_estimates_default(double* out)
+{
+    out[0] = 0.9956844883;
+    out[1] = 0.0005244257 / 3.0;
+    out[2] = 0.003791086;
+    out[3] = 0;
+}
+void orc_error_estimates_rates(double substitutionRate, double deletionRate, double* out)
+{
+    out[0] = 1 - substitutionRate - deletionRate;
+    out[1] = substitutionRate / 3.0;
+    out[2] = deletionRate;
+    out[3] = 0;
+}
+
+// Build MSAByRow + MSAByColumn (MSA.cpp:94-124 then :55-92).  Returns handle or NULL; *err gets the code.
+void* orc_msa_build(int64_t n_reads, const int32_t* ref_start, const int32_t* ref_end, const int64_t* base_off,
+                    const char* cigar, const char* nuc, const uint8_t* qual, const uint8_t* subqv,
+                    const uint8_t* delqv, const uint8_t* insqv, const int32_t* thresholds /*qual,del,sub,ins*/,
+                    int* err)
+{
+    std::unique_ptr<Msa> m(new Msa);
+    const Thresholds thr{thresholds[0], thresholds[1], thresholds[2], thresholds[3]};
+    // UpdateBoundaries over all reads first (MSA.cpp:96-97,138-142)
+    for (int64_t r = 0; r < n_reads; ++r) {
+        m->begin0 = std::min(m->begin0, ref_start[r]);
+        m->end0 = std::max(m->end0, ref_end[r]);
+    }
+    if (n_reads == 0) { m->begin0 = INT_MAX; m->end0 = 0; m->W = 0; *err = ORC_OK; return m.release(); }
+    m->W = m->end0 - m->begin0;
+    const int W = m->W;
+    m->rows.resize(n_reads);
+    // AddRead, MSA.cpp:144-186
+    for (int64_t r = 0; r < n_reads; ++r) {
+        Row& row = m->rows[r];
+        row.bases.assign(W, ' ');
+        int pos = ref_start[r] - m->begin0;
+        std::string insertion;
+        auto check_insertion = [&]() {
+            if (insertion.empty()) return;
+            row.ins[pos] = insertion;
+            insertion.clear();
+        };
+        for (int64_t i = base_off[r]; i < base_off[r + 1]; ++i) {
+            switch (cigar[i]) {
+                case 'X':
+                case '=': {
+                    check_insertion();
+                    if (pos >= W) { *err = ORC_OUT_OF_WINDOW; return nullptr; }  // reference: UB write
+                    const bool ok = meets(thr.qual, qual, i) && meets(thr.del, delqv, i) &&
+                                    meets(thr.sub, subqv, i) && meets(thr.ins, insqv, i);
+                    row.bases[pos++] = ok ? nuc[i] : 'N';
+                    break;
+                }
+                case 'D':
+                    check_insertion();
+                    if (pos >= W) { *err = ORC_OUT_OF_WINDOW; return nullptr; }
+                    row.bases[pos++] = '-';
+                    break;
+                case 'I':
+                    insertion += nuc[i];
+                    break;
+                case 'P':
+                case 'S':
+                    check_insertion();
+                    break;
+                default:
+                    *err = ORC_BAD_CIGAR;  // "Unexpected cigar", MSA.cpp:182
+                    return nullptr;
+            }
+        }
+        // a trailing insertion is dropped: no flush after the loop (MSA.cpp:158-185)
+    }
+    // MSAByColumn ctor, MSA.cpp:55-92
+    m->nuc.assign((size_t)W * 6, 0);
+    m->col_ins.resize(W);
+    for (const auto& row : m->rows) {
+        for (int c = 0; c < W; ++c) {
+            const char ch = row.bases[c];
+            if (ch == ' ') continue;
+            const int t = nuc_tag(ch);
+            if (t == 255) { *err = ORC_BAD_BASE; return nullptr; }  // "Unexpected base", MSA.cpp:85
+            ++m->nuc[(size_t)c * 6 + t];
+        }
+        for (const auto& kv : row.ins)
+            if (kv.first >= 0 && kv.first < W) ++m->col_ins[kv.first][kv.second];
+    }
+    *err = ORC_OK;
+    return m.release();
+}
+
+void orc_msa_free(void* h) { delete static_cast<Msa*>(h); }
+
+// MSAByRow::BeginPos()/EndPos() after construction are 1-based (MSA.cpp:107-108);
+// MSAByColumn::BeginPos()/EndPos() are 0-based again (MSA.cpp:57-58).
+int orc_msa_begin1(void* h) { return static_cast<Msa*>(h)->begin0 + 1; }
+int orc_msa_end1(void* h) { return static_cast<Msa*>(h)->end0 + 1; }
+int orc_msa_width(void* h) { return static_cast<Msa*>(h)->W; }
+
+void orc_msa_nuc_counts(void* h, int32_t* out /*[W][6]*/)
+{
+    Msa* m = static_cast<Msa*>(h);
+    std::memcpy(out, m->nuc.data(), m->nuc.size() * sizeof(int32_t));
+}
+
+// Row chars, for the literal cross-checks.  out is [n_reads][W].
+void orc_msa_rows(void* h, char* out)
+{
+    Msa* m = static_cast<Msa*>(h);
+    for (size_t r = 0; r < m->rows.size(); ++r) std::memcpy(out + r * m->W, m->rows[r].bases.data(), m->W);
+}
+
+// Dense form of MSAByRow::CodonsAt(i) for i = 0..W-1 (MSA.cpp:126-136): out[i][64].
+void orc_msa_codon_counts(void* h, int32_t* out)
+{
+    Msa* m = static_cast<Msa*>(h);
+    std::memset(out, 0, (size_t)m->W * 64 * sizeof(int32_t));
+    for (int i = 0; i < m->W; ++i)
+        for (const auto& kv : codons_at(*m, i)) out[(size_t)i * 64 + codon_index(kv.first)] = kv.second;
+}
+
+// MSAColumn::Coverage (MSA.cpp:221) and MaxBase (MSA.inl:68-80): first max over A C G T - N; 'N' -> ' '
+int orc_col_coverage(void* h, int col)
+{
+    Msa* m = static_cast<Msa*>(h);
+    int s = 0;
+    for (int t = 0; t < 6; ++t) s += m->nuc[(size_t)col * 6 + t];
+    return s;
+}
+char orc_col_maxbase(void* h, int col)
+{
+    Msa* m = static_cast<Msa*>(h);
+    const int32_t* c = &m->nuc[(size_t)col * 6];
+    const int best = (int)(std::max_element(c, c + 6) - c);
+    return best == 5 ? ' ' : kTagChar[best];
+}
+// Insertion histogram of one column (MSAColumn::Insertions, MSA.inl:103): writes "SEQ\tCOUNT\n" lines.
+int orc_col_insertions(void* h, int col, char* buf, int buflen)
+{
+    Msa* m = static_cast<Msa*>(h);
+    std::string s;
+    for (const auto& kv : m->col_ins[col]) s += kv.first + "\t" + std::to_string(kv.second) + "\n";
+    if ((int)s.size() + 1 > buflen) return -(int)s.size() - 1;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+// Number of codon positions the caller visits: i = begin; i < end-2; (i-begin)%3==0
+// (src/AminoAcidCaller.cpp:90-94, :417-423).
+int64_t orc_count_positions(int n_genes, const int32_t* gene_begin, const int32_t* gene_end)
+{
+    int64_t P = 0;
+    for (int g = 0; g < n_genes; ++g)
+        for (int i = gene_begin[g]; i < gene_end[g] - 2; ++i)
+            if ((i - gene_begin[g]) % 3 == 0) ++P;
+    return P;
+}
+
+struct orc_position
+{
+    int32_t gene;         // gene index
+    int32_t i;            // 1-based reference position of the codon start (loop variable)
+    int32_t aa_pos;       // 1 + relPos/3
+    int32_t win_pos;      // i - BeginPos1
+    int32_t coverage;     // sum of codon counts
+    int32_t ref_codon;    // codon index or -1 (not set / not a codon)
+    int32_t alt_codon;    // altRefCodon index or -1
+    int32_t maj_codon;    // FindMajorityCodon result index or -1
+    int32_t maj_count;
+    int32_t skipped;      // 1 when the reference 'continue's before the cell loop
+};
+struct orc_cell
+{
+    int32_t position;     // index into positions
+    int32_t codon;        // codon index
+    int32_t count;
+    int32_t significant;  // p < alpha with alpha = (float)0.01 (AminoAcidCaller.h:108)
+    int32_t variable;     // frequency < 0.8
+    int32_t pad;
+    double expected;
+    double p;             // Bonferroni-corrected, clipped to 1 (AminoAcidCaller.cpp:481-488)
+    double frequency;
+};
+
+// AminoAcidCaller::CountNumberOfTests (src/AminoAcidCaller.cpp:86-103) followed by the cell loop of
+// AminoAcidCaller::CallVariants (:397-497).  n_genes == 0 -> one "Unnamed ORF" [BeginPos1, EndPos1) (:402-405).
+// ref_seq NULL/empty -> no reference (:411).  err_model = {Match, Substitution, Deletion}.
+// positions must hold orc_count_positions() entries, cells 64x that.  Returns number of cells, or <0.
+int64_t orc_call(void* h, int n_genes, const int32_t* gene_begin, const int32_t* gene_end, const char* ref_seq,
+                 const double* err_model, double maximal_perc, orc_position* positions, orc_cell* cells,
+                 int32_t* number_of_tests)
+{
+    Msa* m = static_cast<Msa*>(h);
+    const int begin1 = m->begin0 + 1, end1 = m->end0 + 1;
+    std::vector<int32_t> gb, ge;
+    if (n_genes == 0) {
+        gb.push_back(begin1);
+        ge.push_back(end1);
+    } else {
+        gb.assign(gene_begin, gene_begin + n_genes);
+        ge.assign(gene_end, gene_end + n_genes);
+    }
+    const std::string reference = ref_seq ? std::string(ref_seq) : std::string();
+    const bool hasReference = !reference.empty();
+    const double Match = err_model[0], Substitution = err_model[1], Deletion = err_model[2];
+    static const float alpha = 0.01f;  // AminoAcidCaller.h:108
+
+    // CountNumberOfTests, :86-103
+    int numberOfTests = 0;
+    for (size_t g = 0; g < gb.size(); ++g)
+        for (int i = gb[g]; i < ge[g] - 2; ++i) {
+            if ((i - gb[g]) % 3 != 0) continue;
+            numberOfTests += (int)codons_at(*m, i - begin1).size();
+        }
+    if (numberOfTests == 0) numberOfTests = 1;
+    *number_of_tests = numberOfTests;
+
+    // Probability, :325-339
+    auto probability = [&](const std::string& a, const std::string& b) {
+        if (a.size() != b.size()) return 0.0;
+        double p = 1;
+        for (size_t k = 0; k < a.size(); ++k) {
+            if (a[k] == '-' || b[k] == '-')
+                p *= Deletion;
+            else if (a[k] != b[k])
+                p *= Substitution;
+            else
+                p *= Match;
+        }
+        return p;
+    };
+
+    int64_t P = 0, C = 0;
+    for (size_t g = 0; g < gb.size(); ++g) {
+        for (int i = gb[g]; i < ge[g] - 2; ++i) {
+            const int absPos = i - 1;
+            const int relPos = i - gb[g];
+            if (relPos % 3 != 0) continue;
+            const int winPos = i - begin1;
+            orc_position& pos = positions[P];
+            pos.gene = (int)g; pos.i = i; pos.aa_pos = 1 + relPos / 3; pos.win_pos = winPos;
+            pos.ref_codon = pos.alt_codon = pos.maj_codon = -1; pos.maj_count = 0; pos.skipped = 0;
+            const int64_t thisP = P++;
+
+            std::map<std::string, int> codons = codons_at(*m, winPos);  // :435
+            int coverage = 0;
+            for (const auto& kv : codons) coverage += kv.second;
+            pos.coverage = coverage;
+
+            // FindMajorityCodon, :380-395: strict '>' over the lexicographically ordered map; empty -> default
+            std::string mcCodon;
+            int mcCoverage = -1;
+            for (const auto& kv : codons)
+                if (kv.second > mcCoverage) { mcCoverage = kv.second; mcCodon = kv.first; }
+            if (codon_index(mcCodon) < 0) { mcCodon.clear(); mcCoverage = 0; }  // MajorityCall(): Coverage = 0
+            pos.maj_codon = codon_index(mcCodon);
+            pos.maj_count = mcCoverage;
+
+            std::string refCodon, altRefCodon;
+            if (hasReference) {  // :444-458
+                // std::string::substr throws std::out_of_range when absPos > size(); mirror as a skip + error
+                if (absPos < 0 || (size_t)absPos > reference.size()) return ORC_BAD_ARG;
+                refCodon = reference.substr(absPos, 3);
+                if (codon_index(refCodon) < 0) { pos.skipped = 1; continue; }
+                pos.ref_codon = codon_index(refCodon);
+                if (mcCoverage == 0) { pos.skipped = 1; continue; }
+                if (mcCoverage * 100.0 / coverage > maximal_perc) {
+                    altRefCodon = mcCodon;
+                    pos.alt_codon = codon_index(altRefCodon);
+                }
+            } else {  // :459-463
+                if (mcCoverage == 0) { pos.skipped = 1; continue; }
+                refCodon = mcCodon;
+                pos.ref_codon = codon_index(refCodon);
+            }
+
+            for (const auto& kv : codons) {  // :465-497
+                if (refCodon == kv.first) continue;
+                if (!altRefCodon.empty() && altRefCodon == kv.first) continue;
+                const double expected = coverage * probability(refCodon, kv.first);
+                double p = fisher_tiss((int)std::ceil(kv.second), (int)std::ceil(coverage - kv.second),
+                                       (int)std::ceil(expected), (int)std::ceil(coverage - expected)) *
+                           numberOfTests;
+                if (p > 1) p = 1;
+                const double frequency = 1.0 * kv.second / coverage;
+                orc_cell& cell = cells[C++];
+                cell.position = (int32_t)thisP;
+                cell.codon = codon_index(kv.first);
+                cell.count = kv.second;
+                cell.expected = expected;
+                cell.p = p;
+                cell.frequency = frequency;
+                cell.variable = frequency < 0.8;
+                cell.significant = p < alpha;
+                cell.pad = 0;
+            }
+        }
+    }
+    return C;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""GPU parity, pileup: msq_pileup (through the C ABI) against the oracle -- count matrices bit-exact -- on the
+hand-made edge sets, on synthetic workloads, in every kernel mode; plus size-independent properties at the
+bench size.  The device generator must reproduce the host generator bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from minorseq_amd import abi, device, synth
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+EDGE = cases.edge_sets()
+MODES = [abi.MSQ_PILEUP_SIMPLE, abi.MSQ_PILEUP_AUTO]
+
+
+def gpu_counts(ctx, reads, thr, mode, begin0=None, W=None):
+    dr = device.upload(device.pack_host(reads), ctx.device)
+    b, e = device.window_bounds(ctx, dr)
+    if begin0 is None:
+        begin0, W = b, (e - b if dr.n_reads else 0)
+    nuc, codon = device.pileup(ctx, dr, abi.QvThresholds.make(*thr), begin0, W, mode=mode)
+    return (b, e), nuc.cpu().numpy()[:W * 6].reshape(W, 6), codon.cpu().numpy()[:W * 64].reshape(W, 64)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", sorted(EDGE))
+def test_edge_sets(ctx, name, mode):
+    reads, thr = EDGE[name]
+    m = orc.Msa(reads, thr)
+    (b, e), nuc, codon = gpu_counts(ctx, reads, (thr[0], thr[1], thr[2], thr[3]), mode)
+    assert (b + 1, e + 1) == (m.begin1, m.end1)  # MSAByRow::BeginPos/EndPos are 1-based (src/MSA.cpp:107-108)
+    assert (nuc == m.nuc_counts()).all()
+    assert (codon == m.codon_counts()).all()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name,n,rich,thr", [
+    ("pol_100k", 3000, False, (-1, -1, -1, -1)),
+    ("pol_100k", 1500, False, (75, -1, -1, -1)),
+    ("pol_100k", 1500, True, (-1, -1, 42, -1)),
+    ("pol_100k", 1000, True, (70, 50, 42, 55)),
+    ("hiv_1k", 400, False, (-1, -1, -1, -1)),
+    ("amp20k_10m", 60, False, (-1, -1, -1, -1)),
+])
+def test_synthetic_vs_oracle(ctx, name, n, rich, thr, mode):
+    wl = synth.workload(name, n_reads=n, rich_qv=rich)
+    reads = wl.host_reads(0, n)
+    m = orc.Msa(reads, thr)
+    _, nuc, codon = gpu_counts(ctx, reads, thr, mode)
+    assert (nuc == m.nuc_counts()).all()
+    assert (codon == m.codon_counts()).all()
+
+
+@pytest.mark.parametrize("name,rich", [("pol_100k", False), ("hiv_1k", True)])
+def test_device_generator_matches_host_generator(ctx, name, rich):
+    wl = synth.workload(name, n_reads=500, rich_qv=rich)
+    host = device.pack_host(wl.host_reads(100, 300))
+    dev = device.download(device.synth_device(ctx, wl, 100, 300))
+    assert dev["n_groups"] == host["n_groups"]
+    for f in device.DeviceReads.FIELDS:
+        if host[f] is None:
+            assert dev[f] is None or not rich
+            continue
+        assert (np.asarray(dev[f]) == np.asarray(host[f])).all(), f
+
+
+def test_errors_surface(ctx):
+    L = abi.lib()
+    thr = abi.QvThresholds.make()
+    # "Unexpected base" (src/MSA.cpp:85) is raised on the device path as a deferred error
+    dr = device.upload(device.pack_host(cases.make_reads([(0, "===", "ARG")])), ctx.device)
+    nuc, codon = device.alloc_counts(ctx, 3)
+    abi.check(L.msq_pileup(ctx.h, dr.view, thr, 0, 3, nuc.data_ptr(), codon.data_ptr(), abi.MSQ_PILEUP_AUTO))
+    assert L.msq_pileup_check(ctx.h) == abi.MSQ_ERR_BASE
+    assert L.msq_pileup_check(ctx.h) == abi.MSQ_OK  # cleared
+    # ... but not when the QV mask turns the base into 'N' first (MSA.cpp:163-166)
+    nuc.zero_(); codon.zero_()
+    device.pileup(ctx, dr, abi.QvThresholds.make(qual=61), 0, 3, nuc, codon)
+    assert nuc.cpu().numpy()[:18].reshape(3, 6)[1].tolist() == [0, 0, 0, 0, 0, 1]
+    # a read outside the stated window
+    dr2 = device.upload(device.pack_host(cases.make_reads([(5, "====", "ACGT")])), ctx.device)
+    abi.check(L.msq_pileup(ctx.h, dr2.view, thr, 6, 3, nuc.data_ptr(), codon.data_ptr(), abi.MSQ_PILEUP_AUTO))
+    assert L.msq_pileup_check(ctx.h) == abi.MSQ_ERR_WINDOW
+    # empty input: bounds are the MSAByRow defaults (include/pacbio/data/MSA.h:83-84)
+    e = device.upload(device.pack_host(cases.make_reads([])), ctx.device)
+    assert device.window_bounds(ctx, e) == (2 ** 31 - 1, 0)
+
+
+def test_bench_size_properties(ctx):
+    """At BASELINE config #2's full size (1e5 x 2843): shard additivity, coverage sums, codon <= nucleotide
+    coverage, quirk columns, and agreement of the kernel modes."""
+    wl = synth.workload("pol_100k")
+    n = wl.n_reads
+    thr = abi.QvThresholds.make()
+    dr = device.synth_device(ctx, wl, 0, n)
+    assert device.window_bounds(ctx, dr) == (2252, 5095)
+    W = wl.W
+    nuc, codon = device.pileup(ctx, dr, thr, 2252, W)
+    nuc_s, codon_s = device.pileup(ctx, dr, thr, 2252, W, mode=abi.MSQ_PILEUP_SIMPLE)
+    assert torch.equal(nuc, nuc_s) and torch.equal(codon, codon_s)
+    N = nuc.cpu().numpy()[:W * 6].reshape(W, 6).astype(np.int64)
+    Cc = codon.cpu().numpy()[:W * 64].reshape(W, 64).astype(np.int64)
+    assert (N.sum(1) == n).all()  # every read spans the amplicon: coverage incl. '-' and N
+    assert Cc[0].sum() == 0 and Cc[W - 2:].sum() == 0 and (Cc[1:W - 2].sum(1) > 0.97 * n).all()
+    acgt = N[:, :4].sum(1)
+    assert (Cc.sum(1) <= np.minimum(acgt, np.minimum(np.roll(acgt, -1), np.roll(acgt, -2)))).all()
+    # first base of the codon histogram marginalises to at most the nucleotide count
+    assert (Cc.reshape(W, 4, 16).sum(2) <= N[:, :4]).all()
+    # shards add up (the multi-GPU path is exactly this + an all-reduce)
+    acc_n, acc_c = device.alloc_counts(ctx, W)
+    for first, cnt in ((0, 30000), (30000, 50000), (80000, 20000)):
+        part = device.synth_device(ctx, wl, first, cnt)
+        device.pileup(ctx, part, thr, 2252, W, acc_n, acc_c)
+    assert torch.equal(acc_n, nuc) and torch.equal(acc_c, codon)
+    # the oracle on a prefix the CPU finishes in seconds
+    k = 2000
+    m = orc.Msa(wl.host_reads(0, k))
+    pn, pc = device.pileup(ctx, device.synth_device(ctx, wl, 0, k), thr, 2252, W)
+    assert (pn.cpu().numpy()[:W * 6].reshape(W, 6) == m.nuc_counts()).all()
+    assert (pc.cpu().numpy()[:W * 64].reshape(W, 64) == m.codon_counts()).all()
