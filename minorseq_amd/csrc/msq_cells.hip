@@ -282,6 +282,12 @@ __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restri
     if (out_expected) out_expected[p * 64 + lane] = expected;
 }
 
+// numberOfTests == 0 ? 1 : numberOfTests, src/AminoAcidCaller.cpp:102 (applied after every reader of the raw sum)
+__global__ void finalize_tests_kernel(int32_t* __restrict__ n_tests)
+{
+    if (*n_tests == 0) *n_tests = 1;
+}
+
 extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t* d_codon, const msq_error_model* em,
                               double maximal_perc, msq_position* d_positions, double* d_p, double* d_expected,
                               int32_t* d_n_tests)
@@ -291,7 +297,11 @@ extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t
         return msq_fail(MSQ_ERR_RANGE, "basic_string::substr: a gene position lies outside the reference sequence");
     MSQ_HIP(hipSetDevice(ctx->device));
     MSQ_HIP(hipMemsetAsync(d_n_tests, 0, sizeof(int32_t), ctx->stream));
-    if (plan->P == 0) return MSQ_OK;
+    if (plan->P == 0) {
+        hipLaunchKernelGGL(finalize_tests_kernel, dim3(1), dim3(1), 0, ctx->stream, d_n_tests);
+        MSQ_HIP(hipGetLastError());
+        return MSQ_OK;
+    }
     if (!d_codon || !d_positions || !d_p) return msq_fail(MSQ_ERR_ARG, "msq_call_cells: NULL device buffer");
     if (!ctx->d_lfact) {
         int rc = msq_lfact_reserve(ctx, 4096);
@@ -305,6 +315,8 @@ extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t
     hipLaunchKernelGGL(call_cells_kernel, dim3(blocks), dim3(256), 0, ctx->stream, plan->d_pos, plan->P, plan->begin1,
                        plan->W, plan->has_reference ? 1 : 0, d_codon, lf, *em, maximal_perc, d_n_tests, d_positions, d_p,
                        d_expected, ctx->d_err);
+    MSQ_HIP(hipGetLastError());
+    hipLaunchKernelGGL(finalize_tests_kernel, dim3(1), dim3(1), 0, ctx->stream, d_n_tests);
     MSQ_HIP(hipGetLastError());
     return MSQ_OK;
 }
