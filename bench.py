@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- juliet pileup + Fisher hot path on MI355X: aligned CCS reads/s and % of the HBM roofline.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pol_1m] [--reads R]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the hot path over one batch of synthetic reads already resident in HBM:
+window bounds -> zero the count matrices -> pileup (nucleotide + codon counts) -> [N > 1: RCCL all-reduce of the
+integer count matrices] -> CountNumberOfTests + per-(position, codon) Fisher cells.  N > 1 is weak scaling:
+every rank holds its own shard of `reads` reads of one global sample (global read index = rank * reads + i),
+there is no data-path collective besides the count all-reduce the north star prescribes.
+
+Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the read-streaming pileup kernel) timed with
+HIP events on its own stream inside the timed region; `cpu_baseline` is the oracle (CPU restatement of the
+reference path) on a bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pol_1m", help="pol_1m (default: 1M x 2843, north-star target), pol_100k, "
+                    "hiv_mix_200k, amp20k_10m")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
+    ap.add_argument("--qualqv", type=int, default=-1, help="QUALQV threshold (env var of the reference); -1 = unset")
+    ap.add_argument("--mode", default="auto", choices=["auto", "simple", "stream"])
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the CPU baseline sample (0 = skip)")
+    return ap.parse_args()
+
+
+def load_traffic(kernel, workload, reads):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            for e in json.load(f)["entries"]:
+                if e["kernel"] == kernel and e["workload"] == workload and e["reads"] == reads:
+                    return e["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def cpu_baseline(wl, sample):
+    """The oracle's juliet path (MSAByRow + MSAByColumn + CountNumberOfTests + CallVariants) on `sample` reads."""
+    from oracle import orc
+    reads = wl.host_reads(0, sample)
+    gb, ge = wl.gene_arrays()
+    t0 = time.perf_counter()
+    m = orc.Msa(reads)
+    m.call(gb, ge, wl.reference if wl.use_reference else "")
+    dt = time.perf_counter() - t0
+    m.close()
+    return {"value": sample / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the same synthetic workload, %.1f s on one host core (oracle/liborc.so)" % (sample, dt)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from minorseq_amd import abi, device, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    wl = synth.workload(a.workload)
+    reads = a.reads or wl.n_reads
+    ctx = device.Ctx(local)
+    L = abi.lib()
+    thr = abi.QvThresholds.make(qual=a.qualqv)
+    mode = {"auto": abi.MSQ_PILEUP_AUTO, "simple": abi.MSQ_PILEUP_SIMPLE, "stream": abi.MSQ_PILEUP_STREAM}[a.mode]
+
+    # ---- setup (untimed): reads into HBM, plan, log-factorial table
+    dr = device.synth_device(ctx, wl, rank * reads, reads)
+    n_bases = dr.n_groups * 32
+    b0, e0 = device.window_bounds(ctx, dr)
+    if world > 1:
+        t = torch.tensor([-b0, e0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        b0, e0 = -int(t[0]), int(t[1])
+    W = e0 - b0
+    gb, ge = wl.gene_arrays()
+    plan = device.Plan(ctx, gb, ge, wl.reference if wl.use_reference else "", b0 + 1, W)
+    ctx.lfact_reserve(2 * reads * world + 2)
+    counts = torch.zeros(W * 70, dtype=torch.int32, device="cuda")  # [W][6] nucleotide then [W][64] codon, one buffer
+    nuc, codon = counts[:W * 6], counts[W * 6:]
+    em = abi.ErrorModel()
+    abi.check(L.msq_error_model_default(C.byref(em)))
+
+    def step():
+        bb, ee = device.window_bounds(ctx, dr)  # MSAByRow pass 1 (host needs W to size the launch)
+        if world > 1:
+            t = torch.tensor([-bb, ee], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        counts.zero_()
+        abi.check(L.msq_pileup(ctx.h, dr.view, thr, b0, W, nuc.data_ptr(), codon.data_ptr(), mode))
+        if world > 1:
+            dist.all_reduce(counts)  # RCCL sum of the integer count matrices over xGMI
+        abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
+                                   plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    abi.check(L.msq_pileup_check(ctx.h))
+    abi.check(L.msq_call_check(ctx.h))
+    abi.check(L.msq_timing_enable(ctx.h, a.steps))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    abi.check(L.msq_pileup_check(ctx.h))
+    abi.check(L.msq_call_check(ctx.h))
+    ms = (C.c_float * a.steps)()
+    n_ms = C.c_int32(0)
+    abi.check(L.msq_timing_read(ctx.h, ms, a.steps, C.byref(n_ms)))
+    abi.check(L.msq_timing_enable(ctx.h, 0))
+    kernel_ms = sum(ms[:n_ms.value]) / max(1, n_ms.value)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        alg_bytes = wl.algorithmic_bytes(n_reads=reads)  # N * (1.001 * W * 1.5 + 12)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        kernel_name = "pileup_simple_kernel" if a.mode == "simple" else "pileup_kernel"
+        out = {
+            "metric": "aligned CCS reads/sec (pileup+Fisher, node)",
+            "value": reads * world / (dt / a.steps),
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 counts, f64 Fisher",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d reads/GPU x %d columns (HXB2 pol, 1%% minors), QUALQV=%s" % (
+                wl.name, reads, W, "unset" if a.qualqv < 0 else a.qualqv), "mode": a.mode,
+                "bases_per_gpu": int(n_bases), "codon_positions": plan.P, "number_of_tests": int(plan.n_tests.item())},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kernel_name, wl.name, reads),
+                         "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
+        }
+        if world == 1 and a.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(wl, min(a.cpu_sample, reads))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

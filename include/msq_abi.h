@@ -130,6 +130,13 @@ int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thres
  * Synchronises. */
 int msq_pileup_check(msq_ctx* ctx);
 
+/* Measurement aid (no counterpart in the reference): while enabled, every msq_pileup records a HIP event pair
+ * on the context's stream around its dominant kernel launch (the one that streams the packed reads), up to
+ * max_records pairs; msq_timing_read synchronises, returns the elapsed ms of each pair and resets.
+ * max_records == 0 disables.  bench.py uses this for the roofline figure. */
+int msq_timing_enable(msq_ctx* ctx, int32_t max_records);
+int msq_timing_read(msq_ctx* ctx, float* ms_out, int32_t capacity, int32_t* n_out);
+
 /* ------------------------------------------------------------------------------------------ cell testing
  * A plan fixes which (gene, codon position) pairs AminoAcidCaller::CallVariants visits
  * (src/AminoAcidCaller.cpp:413-427): for each gene, i = begin; i < end-2; (i-begin)%3==0, 1-based.

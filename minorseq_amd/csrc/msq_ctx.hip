@@ -27,6 +27,8 @@ int msq_fail(int code, const char* fmt, ...)
 
 extern "C" const char* msq_last_error(void) { return g_err; }
 
+static void timing_release(msq_ctx* ctx);
+
 extern "C" int msq_ctx_create(int device, msq_ctx** out)
 {
     if (!out) return msq_fail(MSQ_ERR_ARG, "msq_ctx_create: out is NULL");
@@ -58,6 +60,7 @@ extern "C" int msq_ctx_destroy(msq_ctx* ctx)
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_lfact) (void)hipFree(ctx->d_lfact);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    timing_release(ctx);
     delete ctx;
     return MSQ_OK;
 }
@@ -113,6 +116,54 @@ extern "C" int msq_memcpy_d2h(msq_ctx* ctx, void* h_dst, const void* d_src, size
     if (bytes) MSQ_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MSQ_HIP(hipStreamSynchronize(ctx->stream));
     return MSQ_OK;
+}
+
+static void timing_release(msq_ctx* ctx)
+{
+    for (auto e : ctx->ev_begin) (void)hipEventDestroy(e);
+    for (auto e : ctx->ev_end) (void)hipEventDestroy(e);
+    ctx->ev_begin.clear();
+    ctx->ev_end.clear();
+    ctx->ev_used = 0;
+}
+
+extern "C" int msq_timing_enable(msq_ctx* ctx, int32_t max_records)
+{
+    if (!ctx || max_records < 0) return msq_fail(MSQ_ERR_ARG, "msq_timing_enable: bad argument");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    timing_release(ctx);
+    for (int i = 0; i < max_records; ++i) {
+        hipEvent_t a, b;
+        MSQ_HIP(hipEventCreate(&a));
+        MSQ_HIP(hipEventCreate(&b));
+        ctx->ev_begin.push_back(a);
+        ctx->ev_end.push_back(b);
+    }
+    return MSQ_OK;
+}
+
+extern "C" int msq_timing_read(msq_ctx* ctx, float* ms_out, int32_t capacity, int32_t* n_out)
+{
+    if (!ctx || !n_out || (capacity > 0 && !ms_out)) return msq_fail(MSQ_ERR_ARG, "msq_timing_read: bad argument");
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    int n = ctx->ev_used < capacity ? ctx->ev_used : capacity;
+    for (int i = 0; i < n; ++i) MSQ_HIP(hipEventElapsedTime(&ms_out[i], ctx->ev_begin[i], ctx->ev_end[i]));
+    *n_out = n;
+    ctx->ev_used = 0;
+    return MSQ_OK;
+}
+
+void msq_timing_mark_begin(msq_ctx* ctx)
+{
+    if (ctx->ev_used < (int)ctx->ev_begin.size()) (void)hipEventRecord(ctx->ev_begin[ctx->ev_used], ctx->stream);
+}
+void msq_timing_mark_end(msq_ctx* ctx)
+{
+    if (ctx->ev_used < (int)ctx->ev_begin.size()) {
+        (void)hipEventRecord(ctx->ev_end[ctx->ev_used], ctx->stream);
+        ++ctx->ev_used;
+    }
 }
 
 int msq_scratch(msq_ctx* ctx, size_t bytes, void** out)

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "../../include/msq_abi.h"
 
@@ -27,7 +28,14 @@ struct msq_ctx {
     // scratch owned by the context, grown on demand
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    // measurement aid: event pairs around the dominant pileup kernel (msq_timing_enable)
+    std::vector<hipEvent_t> ev_begin, ev_end;
+    int ev_used = 0;
 };
+
+// Record the begin / end event of the next timing slot (no-ops when timing is off or the slots are used up).
+void msq_timing_mark_begin(msq_ctx* ctx);
+void msq_timing_mark_end(msq_ctx* ctx);
 
 void msq_set_error(const char* fmt, ...);
 int msq_fail(int code, const char* fmt, ...);

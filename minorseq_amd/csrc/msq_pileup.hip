@@ -170,9 +170,11 @@ static int launch_simple(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     QvPlanes q;
     q.plane[0] = R.qual; q.plane[1] = R.delqv; q.plane[2] = R.subqv; q.plane[3] = R.insqv;
     q.thr[0] = thr.qual; q.thr[1] = thr.del; q.thr[2] = thr.sub; q.thr[3] = thr.ins;
+    msq_timing_mark_begin(ctx);
     hipLaunchKernelGGL(pileup_simple_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, ctx->stream, R.ref_start,
                        R.group_off, reinterpret_cast<const uint4*>(R.bop), q, R.n_reads, win_begin0, W, row_bytes,
                        waves, d_nuc, d_codon, ctx->d_err);
+    msq_timing_mark_end(ctx);
     MSQ_HIP(hipGetLastError());
     return MSQ_OK;
 }

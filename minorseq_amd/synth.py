@@ -137,7 +137,7 @@ class Workload:
         return nb * per_base + 12.0 * n
 
 
-_POL = ("Protease", "ReverseTranscriptase", "RNase", "Integrase")
+_POL = ("Protease", "Reverse Transcriptase", "RNase", "Integrase")
 
 
 def _random_reference(length, seed):
