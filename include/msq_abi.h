@@ -67,7 +67,12 @@ int msq_memcpy_d2h(msq_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); 
  *     op 3  'P' / 'S' / padding after the last base of the read: consumes nothing (MSA.cpp:175-180)
  * QV planes hold one byte per base, 32 per group; a NULL plane means "QV absent for every base"
  * (boost::none in ArrayBase, ArrayRead.h:111-114), which always passes (ArrayRead.inl:72-87).
+ * Inside a group the 32 QV bytes are stored transposed as a 4x8 matrix: base k of the group lives at byte
+ * MSQ_QV_BYTE(k) = 4*(k & 7) + (k >> 3).  (Dword i of the group then holds bases i, 8+i, 16+i, 24+i, so a
+ * 4-byte SIMD-within-a-register compare of the 8 dwords yields the 32-bit pass mask in base order.)
  */
+#define MSQ_QV_BYTE(k) ((((k) & 7) << 2) | ((k) >> 3))
+
 typedef struct msq_packed_reads {
     uint64_t n_reads;
     uint64_t n_groups;          /* total groups == group_off[n_reads] */

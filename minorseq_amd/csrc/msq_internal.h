@@ -16,7 +16,7 @@
 enum : int { SYM_BLANK = 0, SYM_A = 1, SYM_C = 2, SYM_G = 3, SYM_T = 4, SYM_GAP = 5, SYM_N = 6 };
 
 // Device-side deferred error word (bit set): reported by msq_pileup_check / msq_call_check.
-enum : uint32_t { DEVERR_BASE = 1u, DEVERR_WINDOW = 2u, DEVERR_RANGE = 4u };
+enum : uint32_t { DEVERR_BASE = 1u, DEVERR_WINDOW = 2u, DEVERR_RANGE = 4u, DEVERR_EXOTIC = 8u };
 
 struct msq_ctx {
     int device = 0;

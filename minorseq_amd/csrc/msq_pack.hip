@@ -103,7 +103,9 @@ extern "C" int msq_pack_reads(uint64_t n_reads, const int32_t* ref_start, const 
                 w[0] = n0; w[1] = n1; w[2] = o0; w[3] = o1;
             }
             for (int k = 0; k < 4; ++k)
-                if (src[k] && len) std::memcpy(dst[k]->data() + g0 * 32, src[k] + b0, (size_t)len);
+                if (src[k])
+                    for (int64_t i = 0; i < len; ++i)  // transposed inside each group, see MSQ_QV_BYTE
+                        (*dst[k])[(g0 + (uint64_t)(i >> 5)) * 32 + MSQ_QV_BYTE(i & 31)] = src[k][b0 + i];
         }
         msq_packed_reads& v = p->view;
         v.n_reads = n_reads;

@@ -73,7 +73,7 @@ __device__ __forceinline__ bool meets_qv(const QvPlanes& q, uint64_t base_index)
 
 __global__ __launch_bounds__(256) void pileup_simple_kernel(
     const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ group_off, const uint4* __restrict__ bop,
-    QvPlanes qv, uint64_t n_reads, int32_t win_begin0, int32_t W, int32_t row_bytes, int32_t waves_per_wg,
+    QvPlanes qv, uint64_t n_reads, uint64_t read_stride, int32_t win_begin0, int32_t W, int32_t row_bytes, int32_t waves_per_wg,
     uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon, uint32_t* __restrict__ err)
 {
     extern __shared__ __align__(16) uint8_t lds[];
@@ -84,8 +84,9 @@ __global__ __launch_bounds__(256) void pileup_simple_kernel(
     uint32_t my_err = 0;
 
     for (uint64_t it = 0; it < iters; ++it) {
-        const uint64_t r = it * total_waves + (uint64_t)blockIdx.x * waves_per_wg + wave;
-        const bool active = r < n_reads;
+        const uint64_t slot = it * total_waves + (uint64_t)blockIdx.x * waves_per_wg + wave;
+        const bool active = slot < n_reads;
+        const uint64_t r = slot * read_stride;  // stride > 1: a strided sample of the reads
         for (int c = lane * 4; c < row_bytes; c += 256) *reinterpret_cast<uint32_t*>(row + c) = 0;  // MSARow(size): ' '
         __syncthreads();
         if (active) {
@@ -111,13 +112,13 @@ __global__ __launch_bounds__(256) void pileup_simple_kernel(
                     const uint32_t code = ((w.x >> k) & 1u) | (((w.y >> k) & 1u) << 1);
                     int sym;
                     if (op == 0) {
-                        sym = meets_qv(qv, g * 32 + k) ? (int)(SYM_A + code) : (int)SYM_N;  // MSA.cpp:163-166
+                        sym = meets_qv(qv, g * 32 + MSQ_QV_BYTE(k)) ? (int)(SYM_A + code) : (int)SYM_N;  // MSA.cpp:163-166
                     } else if (code == 0) {
                         sym = SYM_GAP;  // 'D', MSA.cpp:168-171
                     } else if (code == 1) {
                         sym = SYM_N;  // literal 'N' nucleotide: 'N' whether or not the QV passes
                     } else {
-                        const bool ok = meets_qv(qv, g * 32 + k);
+                        const bool ok = meets_qv(qv, g * 32 + MSQ_QV_BYTE(k));
                         if (code == 2) {
                             if (ok) my_err |= DEVERR_BASE;  // "Unexpected base", MSA.cpp:85
                             sym = SYM_N;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void pileup_simple_kernel(
 }
 
 static int launch_simple(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
-                         int32_t W, uint32_t* d_nuc, uint32_t* d_codon)
+                         int32_t W, uint32_t* d_nuc, uint32_t* d_codon, uint64_t n_reads, uint64_t stride, bool timed)
 {
     const int32_t row_bytes = ((W + 2 + 15) / 16) * 16;
     int waves = 150 * 1024 / row_bytes;
@@ -164,19 +165,26 @@ static int launch_simple(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     if (lds > 48 * 1024)
         MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pileup_simple_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    uint64_t blocks = (R.n_reads + waves - 1) / waves;
+    uint64_t blocks = (n_reads + waves - 1) / waves;
     const uint64_t cap = (uint64_t)ctx->n_cu * 8;
     if (blocks > cap) blocks = cap;
     QvPlanes q;
     q.plane[0] = R.qual; q.plane[1] = R.delqv; q.plane[2] = R.subqv; q.plane[3] = R.insqv;
     q.thr[0] = thr.qual; q.thr[1] = thr.del; q.thr[2] = thr.sub; q.thr[3] = thr.ins;
-    msq_timing_mark_begin(ctx);
+    if (timed) msq_timing_mark_begin(ctx);
     hipLaunchKernelGGL(pileup_simple_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, ctx->stream, R.ref_start,
-                       R.group_off, reinterpret_cast<const uint4*>(R.bop), q, R.n_reads, win_begin0, W, row_bytes,
+                       R.group_off, reinterpret_cast<const uint4*>(R.bop), q, n_reads, stride, win_begin0, W, row_bytes,
                        waves, d_nuc, d_codon, ctx->d_err);
-    msq_timing_mark_end(ctx);
+    if (timed) msq_timing_mark_end(ctx);
     MSQ_HIP(hipGetLastError());
     return MSQ_OK;
+}
+
+// The simple kernel over reads 0, stride, 2*stride, ... (n_sample of them): the stream kernel's guide sample.
+int msq_pileup_simple_sample(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
+                             int32_t W, uint64_t n_sample, uint64_t stride, uint32_t* d_nuc, uint32_t* d_codon)
+{
+    return launch_simple(ctx, R, thr, win_begin0, W, d_nuc, d_codon, n_sample, stride, false);
 }
 
 extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,
@@ -188,6 +196,8 @@ extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const m
     if (!d_nuc || !d_codon) return msq_fail(MSQ_ERR_ARG, "msq_pileup: NULL count matrix");
     if (!d_reads->ref_start || !d_reads->group_off || !d_reads->bop) return msq_fail(MSQ_ERR_ARG, "msq_pileup: NULL read arrays");
     if (((uintptr_t)d_reads->bop & 15u) != 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup: bop must be 16-byte aligned");
+    if ((((uintptr_t)d_reads->qual | (uintptr_t)d_reads->delqv | (uintptr_t)d_reads->subqv | (uintptr_t)d_reads->insqv) & 15u) != 0)
+        return msq_fail(MSQ_ERR_ARG, "msq_pileup: QV planes must be 16-byte aligned");
     for (int k = 0; k < 4; ++k) {
         const int32_t t = (&thr->qual)[k];
         if (t < -1 || t > 255) return msq_fail(MSQ_ERR_ARG, "msq_pileup: QV threshold %d out of range", t);
@@ -201,7 +211,7 @@ extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const m
         if (mode == MSQ_PILEUP_STREAM)
             return msq_fail(MSQ_ERR_ARG, "msq_pileup: streaming kernel not applicable (W=%d, flags=%u)", W, d_reads->flags);
     }
-    return launch_simple(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon);
+    return launch_simple(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon, d_reads->n_reads, 1, true);
 }
 
 extern "C" int msq_pileup_check(msq_ctx* ctx)
@@ -210,10 +220,12 @@ extern "C" int msq_pileup_check(msq_ctx* ctx)
     uint32_t e = 0;
     MSQ_HIP(hipMemcpyAsync(&e, ctx->d_err, sizeof(e), hipMemcpyDeviceToHost, ctx->stream));
     MSQ_HIP(hipStreamSynchronize(ctx->stream));
-    if (e & (DEVERR_BASE | DEVERR_WINDOW)) {
-        const uint32_t keep = e & ~(DEVERR_BASE | DEVERR_WINDOW);
+    if (e & (DEVERR_BASE | DEVERR_WINDOW | DEVERR_EXOTIC)) {
+        const uint32_t keep = e & ~(DEVERR_BASE | DEVERR_WINDOW | DEVERR_EXOTIC);
         MSQ_HIP(hipMemcpyAsync(ctx->d_err, &keep, sizeof(keep), hipMemcpyHostToDevice, ctx->stream));
         MSQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (e & DEVERR_EXOTIC)
+            return msq_fail(MSQ_ERR_ARG, "packed reads hold op-1 codes 2/3 but flags lack MSQ_READS_HAS_EXOTIC");
         if (e & DEVERR_WINDOW) return msq_fail(MSQ_ERR_WINDOW, "a read reaches outside the MSA window");
         return msq_fail(MSQ_ERR_BASE, "Unexpected base");
     }

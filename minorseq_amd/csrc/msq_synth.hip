@@ -115,7 +115,7 @@ struct GroupWriter {
         n1 |= ((code >> 1) & 1u) << k;
         o0 |= (op & 1u) << k;
         o1 |= ((op >> 1) & 1u) << k;
-        const int w = k >> 2, sh = (k & 3) * 8;
+        const int w = MSQ_QV_BYTE(k) >> 2, sh = (MSQ_QV_BYTE(k) & 3) * 8;
         // static indexing keeps q in registers
 #pragma unroll
         for (int b = 0; b < 8; ++b)

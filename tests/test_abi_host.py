@@ -45,7 +45,10 @@ def test_pack_bit_planes():
     # read 1: T then literal N -> op 1 code 1
     assert bop[2, 0] & 3 == 0b11 and bop[2, 1] & 3 == 0b01 and bop[2, 2] & 3 == 0b10 and bop[2, 3] & 3 == 0
     assert p["flags"] == 0
-    assert p["qual"][:34].tolist() == [60] * 34 and p["qual"][34 + 2:64].tolist() == [0] * 28
+    q = p["qual"].reshape(-1, 32)
+    qv_byte = lambda k: 4 * (k & 7) + (k >> 3)  # MSQ_QV_BYTE
+    assert all(q[0, qv_byte(k)] == 60 for k in range(32))
+    assert [int(q[1, qv_byte(k)]) for k in range(32)] == [60] * 4 + [0] * 28
     assert p["subqv"] is None
 
 
