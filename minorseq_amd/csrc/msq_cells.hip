@@ -204,17 +204,23 @@ __device__ __forceinline__ int codon_count(const uint32_t* __restrict__ codon, i
 }
 
 // CountNumberOfTests, src/AminoAcidCaller.cpp:86-103: sum over positions of the number of distinct codons
-__global__ __launch_bounds__(256) void count_tests_kernel(const int32_t* __restrict__ pos, int64_t P, int32_t begin1,
+__global__ __launch_bounds__(1024) void count_tests_kernel(const int32_t* __restrict__ pos, int64_t P, int32_t begin1,
                                                           int32_t W, const uint32_t* __restrict__ codon,
                                                           int32_t* __restrict__ n_tests)
 {
     const int lane = threadIdx.x & 63;
     const int64_t p = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (p >= P) return;
-    const int win_pos = pos[p * 4 + 1] - begin1;
-    const int cnt = codon_count(codon, win_pos, W, lane);
+    int cnt = 0;
+    if (p < P) cnt = codon_count(codon, pos[p * 4 + 1] - begin1, W, lane);
     const unsigned long long nz = __ballot(cnt > 0);
-    if (lane == 0 && nz) atomicAdd(n_tests, __popcll(nz));
+    __shared__ int s_n[16];
+    if (lane == 0) s_n[threadIdx.x >> 6] = __popcll(nz);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic per block: same-address atomics serialise
+        int n = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) n += s_n[k];
+        if (n) atomicAdd(n_tests, n);
+    }
 }
 
 __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restrict__ pos, int64_t P, int32_t begin1,
@@ -308,7 +314,7 @@ extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t
         if (rc != MSQ_OK) return rc;
     }
     const unsigned blocks = (unsigned)((plan->P + 3) / 4);
-    hipLaunchKernelGGL(count_tests_kernel, dim3(blocks), dim3(256), 0, ctx->stream, plan->d_pos, plan->P, plan->begin1,
+    hipLaunchKernelGGL(count_tests_kernel, dim3((unsigned)((plan->P + 15) / 16)), dim3(1024), 0, ctx->stream, plan->d_pos, plan->P, plan->begin1,
                        plan->W, d_codon, d_n_tests);
     MSQ_HIP(hipGetLastError());
     LFact lf{ctx->d_lfact, ctx->lfact_n};

@@ -24,7 +24,17 @@ __global__ void window_bounds_kernel(const int32_t* __restrict__ ref_start, cons
         lo = min(lo, __shfl_xor(lo, d));
         hi = max(hi, __shfl_xor(hi, d));
     }
+    __shared__ int32_t s_lo[4], s_hi[4];
     if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // one atomic pair per block: same-address atomics serialise
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) {
+            lo = min(lo, s_lo[k]);
+            hi = max(hi, s_hi[k]);
+        }
         atomicMin(&out[0], lo);
         atomicMax(&out[1], hi);
     }
@@ -42,7 +52,7 @@ extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, 
     if (d_reads->n_reads) {
         if (!d_reads->ref_start || !d_reads->ref_end) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds: NULL ref arrays");
         uint64_t blocks = (d_reads->n_reads + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > 256) blocks = 256;
         hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_reads->ref_start,
                            d_reads->ref_end, d_reads->n_reads, (int32_t*)s);
         MSQ_HIP(hipGetLastError());

@@ -26,7 +26,6 @@ namespace {
 
 constexpr int kLevels = 16;          // bit-sliced counter depth: 65535 reads per lane between flushes
 constexpr int kReadsPerLane = 8;     // one Harley-Seal block per batch
-constexpr int kSample = 256;         // reads sampled for the guide
 constexpr int kMaxThreads = 512;
 
 enum QvMode : int { QV_NONE = 0, QV_QUAL = 1, QV_ANY = 2 };
@@ -42,10 +41,9 @@ struct StreamArgs {
     int32_t G;           // 32-column groups: ceil(W / 32)
     int32_t RS;          // read slots: lanes that share a column group
     int32_t RD;          // dwords per LDS row (>= G + 1, multiple of 4)
-    const uint32_t* guide;  // [3][RD]: valid, code bit0, code bit1
     uint32_t* nuc;
     uint32_t* codon;
-    uint32_t* partials;  // [gridDim.x][NC][G*32]
+    uint32_t* partials;  // [gridDim.x][NC + 1][G*32]
     uint32_t* err;
 };
 
@@ -134,21 +132,61 @@ __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
     if (v) __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS traffic).
+__device__ __forceinline__ int wave_inclusive_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// bit-sliced compare: 2 * a > b, per column (a, b: kLevels-deep vertical counters)
+__device__ __forceinline__ uint32_t sliced_twice_gt(const uint32_t (&a)[kLevels], const uint32_t (&b)[kLevels])
+{
+    uint32_t gt = a[kLevels - 1], eq = ~a[kLevels - 1];  // level kLevels of 2a vs 0
+#pragma unroll
+    for (int l = kLevels - 1; l >= 0; --l) {
+        const uint32_t x = l > 0 ? a[l - 1] : 0u;  // level l of 2a
+        gt |= eq & x & ~b[l];
+        eq &= ~(x ^ b[l]);
+    }
+    return gt;
+}
+
+template <int NP>
+struct ChunkData {
+    uint4 w;
+    uint4 qa[NP ? NP : 1], qb[NP ? NP : 1];
+};
+struct ChunkItem {
+    int rr;        // read slot in the batch; >= R: no more work
+    int first;     // first chunk of its read
+    uint64_t gb;   // first group of the chunk
+    uint64_t g1;   // end group of the read
+};
+
 template <int QV, bool COUNT_N>
 __global__ __launch_bounds__(kMaxThreads) void pileup_kernel(StreamArgs a)
 {
+    constexpr int NP = QV == QV_NONE ? 0 : QV == QV_QUAL ? 1 : 4;  // QV planes looked at
+    constexpr int DEPTH = QV == QV_ANY ? 1 : 2;                    // chunks in flight ahead of the one being decoded
     extern __shared__ __align__(16) uint32_t lds[];
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = T >> 6;
     const int RS = a.RS, R = kReadsPerLane * RS, RD = a.RD, G = a.G, W = a.W;
     const int plane_stride = R * RD;  // rows of one plane
+    uint32_t* const gl = lds + 5 * plane_stride;                               // guide words [3][RD]
+    uint64_t* const go = reinterpret_cast<uint64_t*>(gl + 3 * RD + (RD & 1));  // group_off of the batch [R+1]
+    int32_t* const rstart = reinterpret_cast<int32_t*>(go + R + 1);            // ref_start of the batch [R]
     uint32_t my_err = 0;
 
     // ---- phase-2 identity: this lane owns columns [32*cg, 32*cg+32) for reads rs, rs+RS, ...
     const bool p2 = tid < G * RS;
     const int cg = p2 ? tid % G : 0, rs = p2 ? tid / G : 0;
-    const uint32_t gv_lo = a.guide[cg], gv_hi = a.guide[cg + 1];
-    const uint32_t g0_lo = a.guide[RD + cg], g0_hi = a.guide[RD + cg + 1];
-    const uint32_t g1_lo = a.guide[2 * RD + cg], g1_hi = a.guide[2 * RD + cg + 1];
+    uint32_t gv_lo = 0, gv_hi = 0, g0_lo = 0, g0_hi = 0, g1_lo = 0, g1_hi = 0;
     // columns that can start a codon: 1 <= c <= W-3 (MSARow::CodonAt's i > 0, CodingCodonAt's bound; MSA.cpp:193,207)
     uint32_t codon_cols = 0;
     {
@@ -159,77 +197,160 @@ __global__ __launch_bounds__(kMaxThreads) void pileup_kernel(StreamArgs a)
     uint32_t cnt_match[kLevels], cnt_gap[kLevels], cnt_codon[kLevels], cnt_n[kLevels];  // cnt_n dead unless COUNT_N
 #pragma unroll
     for (int l = 0; l < kLevels; ++l) cnt_match[l] = cnt_gap[l] = cnt_codon[l] = cnt_n[l] = 0;
+    for (int i = tid; i < 3 * RD; i += T) gl[i] = 0;
 
     const uint64_t n_batches = (a.n_reads + R - 1) / R;
+    bool learn = true;  // the first batch of this workgroup also teaches it its guide
     for (uint64_t batch = blockIdx.x; batch < n_batches; batch += gridDim.x) {
-        // ---- zero the rows (MSARow(size): all ' ')
+        // ---- zero the rows (MSARow(size): all ' '), fetch the batch's read table
         for (int i = tid * 4; i < 5 * plane_stride; i += T * 4) *reinterpret_cast<uint4*>(&lds[i]) = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i <= R; i += T) {
+            const uint64_t r = min(batch * R + (uint64_t)i, a.n_reads);
+            go[i] = a.group_off[r];
+            if (i < R) rstart[i] = r < a.n_reads ? a.ref_start[r] : 0;
+        }
         __syncthreads();
 
-        // ---- phase 1: read space -> column-space planes in LDS (MSAByRow::AddRead, MSA.cpp:144-186)
-        for (int rr = wave; rr < R; rr += NW) {
-            const uint64_t r = batch * R + rr;
-            if (r >= a.n_reads) break;
-            const uint64_t g0 = a.group_off[r], g1 = a.group_off[r + 1];
-            int col = a.ref_start[r] - a.win_begin0;  // MSA.cpp:148
-            uint32_t* row = &lds[rr * RD];
-            for (uint64_t gb = g0; gb < g1; gb += 64) {
-                const uint64_t g = gb + lane;
-                const bool have = g < g1;
-                uint4 w = make_uint4(0u, 0u, ~0u, ~0u);  // beyond the read: op 3
-                if (have) w = a.bop[g];
-                uint32_t pass = ~0u;  // ArrayBase::MeetQVThresholds, ArrayRead.inl:67-87
-                if (QV != QV_NONE && have) {
+        // ---- phase 1: read space -> column-space planes in LDS (MSAByRow::AddRead, MSA.cpp:144-186).
+        // One wave per read, one lane per 32-base group; the wave's chunks form one software-pipelined stream
+        // with DEPTH chunk loads in flight ahead of the chunk being decoded.
+        auto seek_read = [&](int rr) -> ChunkItem {
+            ChunkItem it;
+            it.rr = R; it.first = 1; it.gb = 0; it.g1 = 0;
+            while (rr < R) {
+                const uint64_t g0 = go[rr], g1 = go[rr + 1];
+                if (g1 > g0) { it.rr = rr; it.gb = g0; it.g1 = g1; break; }
+                rr += NW;
+            }
+            return it;
+        };
+        auto next_item = [&](const ChunkItem& it) -> ChunkItem {
+            if (it.rr >= R) return it;
+            if (it.gb + 64 < it.g1) {
+                ChunkItem n = it;
+                n.gb += 64;
+                n.first = 0;
+                return n;
+            }
+            return seek_read(it.rr + NW);
+        };
+        auto load_chunk = [&](const ChunkItem& it) -> ChunkData<NP> {
+            ChunkData<NP> d;
+            d.w = make_uint4(0u, 0u, ~0u, ~0u);  // beyond the read: op 3
+            const uint64_t g = it.gb + lane;
+            const bool have = it.rr < R && g < it.g1;
+            if (have) d.w = a.bop[g];
 #pragma unroll
-                    for (int k = 0; k < (QV == QV_QUAL ? 1 : 4); ++k)
-                        if (a.thr[k] >= 0 && a.qv[k]) {  // wave-uniform
-                            const uint4 qa = a.qv[k][2 * g], qb = a.qv[k][2 * g + 1];
-                            pass &= qv_pass_mask(qa, qb, a.thr[k]);
-                        }
+            for (int k = 0; k < NP; ++k) {
+                d.qa[k] = d.qb[k] = make_uint4(0, 0, 0, 0);
+                if (have && a.thr[k] >= 0 && a.qv[k]) {
+                    d.qa[k] = a.qv[k][2 * g];
+                    d.qb[k] = a.qv[k][2 * g + 1];
                 }
-                const uint32_t cons = ~w.w;          // ops 0, 1 consume a column
-                const uint32_t is_m = cons & ~w.z;   // op 0: '=' / 'X'
-                const uint32_t op1 = cons & w.z;     // op 1: '-', literal N, exotic
-                if (op1 & w.y) my_err |= DEVERR_EXOTIC;  // exotic codes are the simple kernel's job
-                uint32_t pv = is_m & pass;                          // row char = nucleotide   (MSA.cpp:163-164)
-                uint32_t pn = (is_m & ~pass) | (op1 & w.x & ~w.y);  // row char = 'N'          (MSA.cpp:165-166)
-                uint32_t pd = op1 & ~w.x & ~w.y;                    // row char = '-'          (MSA.cpp:168-171)
-                uint32_t b0 = w.x & pv, b1 = w.y & pv;
-                const int n = __popc(cons);
-                if (cons != (n == 32 ? ~0u : ((1u << n) - 1u))) squeeze5(cons, pv, pn, pd, b0, b1);
-                // column of this lane's first base: wave-exclusive prefix sum of n
-                int incl = n;
+            }
+            return d;
+        };
+
+        ChunkItem items[DEPTH + 1];
+        ChunkData<NP> data[DEPTH + 1];
+        items[0] = seek_read(wave);
+        data[0] = load_chunk(items[0]);
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int t = __shfl_up(incl, d);
-                    if (lane >= d) incl += t;
-                }
-                const int c0 = col + incl - n;
-                col += __shfl(incl, 63);
-                if (n) {
-                    if (c0 < 0 || c0 + n > W) {
-                        my_err |= DEVERR_WINDOW;  // assert(pos >= 0) / write past the row, MSA.cpp:149
-                    } else {
-                        const int word = c0 >> 5, sh = c0 & 31;
-                        uint32_t* p = row + word;
-                        lds_or(p, pv << sh);
-                        lds_or(p + plane_stride, b0 << sh);
-                        lds_or(p + 2 * plane_stride, b1 << sh);
-                        lds_or(p + 3 * plane_stride, pd << sh);
-                        lds_or(p + 4 * plane_stride, pn << sh);
-                        if (sh) {
-                            const int back = 32 - sh;
-                            lds_or(p + 1, pv >> back);
-                            lds_or(p + 1 + plane_stride, b0 >> back);
-                            lds_or(p + 1 + 2 * plane_stride, b1 >> back);
-                            lds_or(p + 1 + 3 * plane_stride, pd >> back);
-                            lds_or(p + 1 + 4 * plane_stride, pn >> back);
-                        }
+        for (int q = 1; q <= DEPTH; ++q) {
+            items[q] = next_item(items[q - 1]);
+            data[q] = load_chunk(items[q]);
+        }
+        int col = 0;
+        while (items[0].rr < R) {
+            const ChunkItem it = items[0];
+            const uint4 w = data[0].w;
+            uint32_t pass = ~0u;  // ArrayBase::MeetQVThresholds, ArrayRead.inl:67-87
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                if (a.thr[k] >= 0 && a.qv[k]) pass &= qv_pass_mask(data[0].qa[k], data[0].qb[k], a.thr[k]);  // wave-uniform
+            // rotate the pipeline and put the next chunk's loads in flight before decoding this one
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) {
+                items[q] = items[q + 1];
+                data[q] = data[q + 1];
+            }
+            items[DEPTH] = next_item(items[DEPTH - 1]);
+            data[DEPTH] = load_chunk(items[DEPTH]);
+
+            if (it.first) col = rstart[it.rr] - a.win_begin0;  // MSA.cpp:148
+            uint32_t* row = &lds[it.rr * RD];
+            const uint32_t cons = ~w.w;          // ops 0, 1 consume a column
+            const uint32_t is_m = cons & ~w.z;   // op 0: '=' / 'X'
+            const uint32_t op1 = cons & w.z;     // op 1: '-', literal N, exotic
+            if (op1 & w.y) my_err |= DEVERR_EXOTIC;  // exotic codes are the simple kernel's job
+            uint32_t pv = is_m & pass;                          // row char = nucleotide   (MSA.cpp:163-164)
+            uint32_t pn = (is_m & ~pass) | (op1 & w.x & ~w.y);  // row char = 'N'          (MSA.cpp:165-166)
+            uint32_t pd = op1 & ~w.x & ~w.y;                    // row char = '-'          (MSA.cpp:168-171)
+            uint32_t b0 = w.x & pv, b1 = w.y & pv;
+            const int n = __popc(cons);
+            if (cons != (n == 32 ? ~0u : ((1u << n) - 1u))) squeeze5(cons, pv, pn, pd, b0, b1);
+            // column of this lane's first base: wave-exclusive prefix sum of n
+            const int incl = wave_inclusive_scan(n);
+            const int c0 = col + incl - n;
+            col += __builtin_amdgcn_readlane(incl, 63);
+            if (n) {
+                if (c0 < 0 || c0 + n > W) {
+                    my_err |= DEVERR_WINDOW;  // assert(pos >= 0) / write past the row, MSA.cpp:149
+                } else {
+                    const int word = c0 >> 5, sh = c0 & 31;
+                    uint32_t* p = row + word;
+                    lds_or(p, pv << sh);
+                    lds_or(p + plane_stride, b0 << sh);
+                    lds_or(p + 2 * plane_stride, b1 << sh);
+                    lds_or(p + 3 * plane_stride, pd << sh);
+                    lds_or(p + 4 * plane_stride, pn << sh);
+                    if (sh) {
+                        const int back = 32 - sh;
+                        lds_or(p + 1, pv >> back);
+                        lds_or(p + 1 + plane_stride, b0 >> back);
+                        lds_or(p + 1 + 2 * plane_stride, b1 >> back);
+                        lds_or(p + 1 + 3 * plane_stride, pd >> back);
+                        lds_or(p + 1 + 4 * plane_stride, pn >> back);
                     }
                 }
             }
         }
         __syncthreads();
+
+        // ---- first batch only: learn the guide = per-column majority base of this batch
+        if (learn) {
+            learn = false;
+            if (p2 && rs == 0) {
+                uint32_t cv[kLevels], c0[kLevels], c1[kLevels];
+#pragma unroll
+                for (int l = 0; l < kLevels; ++l) cv[l] = c0[l] = c1[l] = 0;
+                for (int i0 = 0; i0 < R; i0 += kReadsPerLane) {
+                    uint32_t xv[kReadsPerLane], x0[kReadsPerLane], x1[kReadsPerLane];
+#pragma unroll
+                    for (int i = 0; i < kReadsPerLane; ++i) {
+                        const uint32_t* rw = &lds[(i0 + i) * RD + cg];
+                        xv[i] = rw[0];
+                        x0[i] = rw[plane_stride];
+                        x1[i] = rw[2 * plane_stride];
+                    }
+                    counter_add8(cv, xv);
+                    counter_add8(c0, x0);
+                    counter_add8(c1, x1);
+                }
+                uint32_t any = 0;
+#pragma unroll
+                for (int l = 0; l < kLevels; ++l) any |= cv[l];
+                gl[cg] = any;
+                gl[RD + cg] = any & sliced_twice_gt(c0, cv);
+                gl[2 * RD + cg] = any & sliced_twice_gt(c1, cv);
+            }
+            __syncthreads();
+            if (p2) {
+                gv_lo = gl[cg]; gv_hi = gl[cg + 1];
+                g0_lo = gl[RD + cg]; g0_hi = gl[RD + cg + 1];
+                g1_lo = gl[2 * RD + cg]; g1_hi = gl[2 * RD + cg + 1];
+            }
+        }
 
         // ---- phase 2: column space (MSAByColumn ctor MSA.cpp:55-92 + CodonsAt MSA.cpp:126-136,197-219)
         if (p2) {
@@ -287,10 +408,20 @@ __global__ __launch_bounds__(kMaxThreads) void pileup_kernel(StreamArgs a)
         __syncthreads();
     }
 
-    // ---- flush: transpose the bit-sliced counters, reduce the read slots through LDS, store the partial
-    const int NC = COUNT_N ? 4 : 3;
+    // ---- flush: per column the guide's nucleotide / codon bins (meta), then the bit-sliced counters transposed
+    // and reduced over the read slots through LDS, stored as this workgroup's partial
+    constexpr int NC = COUNT_N ? 4 : 3;
     const int cols = G * 32;
-    uint32_t* acc = lds;
+    uint32_t* const part = a.partials + (size_t)blockIdx.x * (NC + 1) * cols;
+    auto gbit = [&](int plane, int c) -> uint32_t { return (gl[plane * RD + (c >> 5)] >> (c & 31)) & 1u; };
+    for (int c = tid; c < cols; c += T) {
+        const uint32_t v0 = gbit(0, c), v1 = gbit(0, c + 1), v2 = gbit(0, c + 2);
+        const uint32_t k0 = gbit(1, c) | (gbit(2, c) << 1), k1 = gbit(1, c + 1) | (gbit(2, c + 1) << 1),
+                       k2 = gbit(1, c + 2) | (gbit(2, c + 2) << 1);
+        part[(size_t)NC * cols + c] = k0 | (v0 << 2) | (((k0 << 4) | (k1 << 2) | k2) << 8) | ((v0 & v1 & v2) << 14);
+    }
+    __syncthreads();
+    uint32_t* const acc = lds;
     for (int k = 0; k < NC; ++k) {
         for (int i = tid; i < cols; i += T) acc[i] = 0;
         __syncthreads();
@@ -304,63 +435,54 @@ __global__ __launch_bounds__(kMaxThreads) void pileup_kernel(StreamArgs a)
             }
         }
         __syncthreads();
-        uint32_t* dst = a.partials + ((size_t)blockIdx.x * NC + k) * cols;
-        for (int i = tid; i < cols; i += T) dst[i] = acc[i];
+        for (int i = tid; i < cols; i += T) part[(size_t)k * cols + i] = acc[i];
         __syncthreads();
     }
     if (my_err) atomicOr(a.err, my_err);
 }
 
-// Guide planes from the sample's nucleotide counts: the most frequent of A C G T - N per column; only an
-// ACGT winner makes a guide base.
-__global__ void make_guide_kernel(const uint32_t* __restrict__ sample_nuc, int W, int RD, uint32_t* __restrict__ guide)
+// Fold the workgroup partials into the count matrices: matches go to each workgroup's guide nucleotide / codon
+// bin, gaps to '-', Ns to 'N' (bins 4 and 5, NucleotideConversion.h:69-88).  Block = 64 columns x 4 workgroup
+// lanes; blockIdx.y slices the workgroups further.
+__global__ __launch_bounds__(256) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
+                                                            int W, uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon)
 {
-    const int word = blockIdx.x * blockDim.x + threadIdx.x;
-    if (word >= RD) return;
-    uint32_t gv = 0, g0 = 0, g1 = 0;
-    for (int j = 0; j < 32; ++j) {
-        const int c = word * 32 + j;
-        if (c >= W) break;
-        int best = 0;
-        uint32_t bestn = 0;
-        for (int t = 0; t < 6; ++t) {
-            const uint32_t n = sample_nuc[(size_t)c * 6 + t];
-            if (n > bestn) { bestn = n; best = t; }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    const int per = (n_wg + gridDim.y - 1) / gridDim.y;
+    const int wg_lo = blockIdx.y * per, wg_hi = min(n_wg, wg_lo + per);
+    if (c >= W) return;
+    uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0, cod_sum = 0;
+    int cod_idx = -1;
+    for (int wg = wg_lo + sub; wg < wg_hi; wg += 4) {
+        const uint32_t* p = partials + (size_t)wg * (NC + 1) * cols;
+        const uint32_t meta = p[(size_t)NC * cols + c];
+        const uint32_t m = p[c], g = p[(size_t)cols + c], cm = p[(size_t)2 * cols + c];
+        if (m) {  // m > 0 implies a valid guide base
+#pragma unroll
+            for (int k = 0; k < 4; ++k) base[k] += (meta & 3u) == (uint32_t)k ? m : 0u;
         }
-        if (bestn > 0 && best < 4) {
-            gv |= 1u << j;
-            g0 |= (uint32_t)(best & 1) << j;
-            g1 |= (uint32_t)(best >> 1) << j;
+        gap += g;
+        if (NC > 3) nn += p[(size_t)3 * cols + c];
+        if (cm) {
+            const int idx = (int)((meta >> 8) & 63u);
+            if (idx != cod_idx) {
+                if (cod_sum) atomicAdd(&codon[(size_t)c * 64 + cod_idx], cod_sum);
+                cod_idx = idx;
+                cod_sum = 0;
+            }
+            cod_sum += cm;
         }
     }
-    guide[word] = gv;
-    guide[RD + word] = g0;
-    guide[2 * RD + word] = g1;
-}
-
-// Fold the workgroup partials into the count matrices: matches go to the guide's nucleotide / codon bin,
-// gaps to '-', Ns to 'N' (bins 4 and 5, NucleotideConversion.h:69-88).
-__global__ __launch_bounds__(256) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
-                                                            int W, int RD, const uint32_t* __restrict__ guide,
-                                                            uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= W) return;
-    uint32_t s[4] = {0, 0, 0, 0};
-    for (int wg = 0; wg < n_wg; ++wg)
-        for (int k = 0; k < NC; ++k) s[k] += partials[((size_t)wg * NC + k) * cols + c];
-    auto gbit = [&](int plane, int col) -> uint32_t { return (guide[plane * RD + (col >> 5)] >> (col & 31)) & 1u; };
-    auto gcode = [&](int col) -> uint32_t { return gbit(1, col) | (gbit(2, col) << 1); };
-    if (s[0]) nuc[(size_t)c * 6 + gcode(c)] += s[0];  // s[0] > 0 implies a valid guide base here
-    if (s[1]) nuc[(size_t)c * 6 + 4] += s[1];
-    if (NC > 3 && s[3]) nuc[(size_t)c * 6 + 5] += s[3];
-    if (s[2]) codon[(size_t)c * 64 + ((gcode(c) << 4) | (gcode(c + 1) << 2) | gcode(c + 2))] += s[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base[k]) atomicAdd(&nuc[(size_t)c * 6 + k], base[k]);
+    if (gap) atomicAdd(&nuc[(size_t)c * 6 + 4], gap);
+    if (nn) atomicAdd(&nuc[(size_t)c * 6 + 5], nn);
+    if (cod_sum) atomicAdd(&codon[(size_t)c * 64 + cod_idx], cod_sum);
 }
 
 }  // namespace
-
-int msq_pileup_simple_sample(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
-                             int32_t W, uint64_t n_sample, uint64_t stride, uint32_t* d_nuc, uint32_t* d_codon);
 
 int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
                              int32_t W, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
@@ -385,7 +507,8 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
     }
     if (!best_T) return MSQ_OK;
     const int T = best_T, RS = best_RS, RD = ((G + 1 + 3) / 4) * 4, Rb = kReadsPerLane * RS;
-    const size_t lds = std::max((size_t)5 * Rb * RD * 4, (size_t)G * 32 * 4);
+    // rows [5][Rb][RD] | guide [3][RD] (+pad) | group_off [Rb+1] u64 | ref_start [Rb]
+    const size_t lds = (size_t)5 * Rb * RD * 4 + (size_t)(3 * RD + 1) * 4 + (size_t)(Rb + 1) * 8 + (size_t)Rb * 4 + 16;
     const int wg_per_cu = std::max(1, std::min((int)(160 * 1024 / (lds + 512)), 2048 / T));
     const uint64_t n_batches = (R.n_reads + Rb - 1) / Rb;
     const int n_wg = (int)std::min<uint64_t>(n_batches, (uint64_t)ctx->n_cu * wg_per_cu);
@@ -398,26 +521,11 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
     else if (q_on) mode = QV_QUAL;
     const int NC = mode == QV_NONE ? 3 : 4;
 
-    // scratch: sample counts [W][70] | guide [3][RD] | partials [n_wg][NC][G*32]
-    const size_t sample_bytes = (size_t)W * 70 * 4;
-    const size_t guide_off = (sample_bytes + 255) & ~(size_t)255;
-    const size_t part_off = (guide_off + (size_t)3 * RD * 4 + 255) & ~(size_t)255;
-    const size_t total = part_off + (size_t)n_wg * NC * G * 32 * 4;
+    // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
     void* s = nullptr;
-    int rc = msq_scratch(ctx, total, &s);
+    int rc = msq_scratch(ctx, (size_t)n_wg * (NC + 1) * G * 32 * 4, &s);
     if (rc != MSQ_OK) return rc;
-    uint32_t* d_sample = (uint32_t*)s;
-    uint32_t* d_guide = (uint32_t*)((char*)s + guide_off);
-    uint32_t* d_part = (uint32_t*)((char*)s + part_off);
-
-    // guide from a strided sample of the reads
-    MSQ_HIP(hipMemsetAsync(d_sample, 0, sample_bytes, ctx->stream));
-    const uint64_t n_sample = std::min<uint64_t>(R.n_reads, kSample);
-    const uint64_t stride = std::max<uint64_t>(1, R.n_reads / n_sample);
-    rc = msq_pileup_simple_sample(ctx, R, thr, win_begin0, W, n_sample, stride, d_sample, d_sample + (size_t)W * 6);
-    if (rc != MSQ_OK) return rc;
-    hipLaunchKernelGGL(make_guide_kernel, dim3((RD + 63) / 64), dim3(64), 0, ctx->stream, d_sample, W, RD, d_guide);
-    MSQ_HIP(hipGetLastError());
+    uint32_t* d_part = (uint32_t*)s;
 
     StreamArgs a;
     a.ref_start = R.ref_start;
@@ -432,7 +540,6 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
     a.win_begin0 = win_begin0;
     a.W = W;
     a.G = G; a.RS = RS; a.RD = RD;
-    a.guide = d_guide;
     a.nuc = d_nuc;
     a.codon = d_codon;
     a.partials = d_part;
@@ -446,8 +553,10 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
     hipLaunchKernelGGL(kern, dim3(n_wg), dim3(T), lds, ctx->stream, a);
     msq_timing_mark_end(ctx);
     MSQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((W + 255) / 256), dim3(256), 0, ctx->stream, d_part, n_wg, NC, G * 32, W, RD,
-                       d_guide, d_nuc, d_codon);
+    const int col_blocks = (W + 63) / 64;
+    const int slices = std::max(1, std::min(n_wg / 8, (2 * ctx->n_cu + col_blocks - 1) / col_blocks));
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(256), 0, ctx->stream, d_part, n_wg, NC, G * 32, W,
+                       d_nuc, d_codon);
     MSQ_HIP(hipGetLastError());
     *handled = true;
     return MSQ_OK;
