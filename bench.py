@@ -41,12 +41,14 @@ def parse():
     return ap.parse_args()
 
 
-def load_traffic(kernel, workload, reads):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json), or None."""
+def load_traffic(kernel, workload, reads, qualqv):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic.json; rocprofv3 cannot run inside the
+    timed process), or None when no pass was recorded for this exact kernel / workload / size / QV setting."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             for e in json.load(f)["entries"]:
-                if e["kernel"] == kernel and e["workload"] == workload and e["reads"] == reads:
+                if (e["kernel"] == kernel and e["workload"] == workload and e["reads"] == reads
+                        and e.get("qualqv") == (None if qualqv < 0 else qualqv)):
                     return e["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -170,7 +172,7 @@ def main():
                 wl.name, reads, W, "unset" if a.qualqv < 0 else a.qualqv), "mode": a.mode,
                 "bases_per_gpu": int(n_bases), "codon_positions": plan.P, "number_of_tests": int(plan.n_tests.item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kernel_name, wl.name, reads),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kernel_name, wl.name, reads, a.qualqv),
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
         }
         if world == 1 and a.cpu_sample > 0:
