@@ -73,7 +73,7 @@ def main():
     a = parse()
     import torch
     import torch.distributed as dist
-    from minorseq_amd import abi, device, synth
+    from minorseq_amd import abi, device, sharding, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,11 +96,7 @@ def main():
     # ---- setup (untimed): reads into HBM, plan, log-factorial table
     dr = device.synth_device(ctx, wl, rank * reads, reads)
     n_bases = dr.n_groups * 32
-    b0, e0 = device.window_bounds(ctx, dr)
-    if world > 1:
-        t = torch.tensor([-b0, e0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        b0, e0 = -int(t[0]), int(t[1])
+    b0, e0 = sharding.allreduce_bounds(*device.window_bounds(ctx, dr), "cuda")
     W = e0 - b0
     gb, ge = wl.gene_arrays()
     plan = device.Plan(ctx, gb, ge, wl.reference if wl.use_reference else "", b0 + 1, W)
@@ -111,14 +107,10 @@ def main():
     abi.check(L.msq_error_model_default(C.byref(em)))
 
     def step():
-        bb, ee = device.window_bounds(ctx, dr)  # MSAByRow pass 1 (host needs W to size the launch)
-        if world > 1:
-            t = torch.tensor([-bb, ee], dtype=torch.int32, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sharding.allreduce_bounds(*device.window_bounds(ctx, dr), "cuda")  # MSAByRow pass 1 (UpdateBoundaries)
         counts.zero_()
         abi.check(L.msq_pileup(ctx.h, dr.view, thr, b0, W, nuc.data_ptr(), codon.data_ptr(), mode))
-        if world > 1:
-            dist.all_reduce(counts)  # RCCL sum of the integer count matrices over xGMI
+        sharding.allreduce_counts(counts)  # N > 1: RCCL sum of the integer count matrices over xGMI
         abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
                                    plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))
 

@@ -1,0 +1,670 @@
+// msq_front.hpp -- C++ host front of the MI355X pileup + Fisher layer: the reference's MSA / Fisher /
+// AminoAcidCaller interface (same names, argument meaning and error behaviour) on top of the C ABI
+// (include/msq_abi.h).  A maintainer swaps the reference's data/statistics layer for this header + libmsq_hip.so;
+// the callers (JulietWorkflow::AminoPhasing / ::Error, Fuse) keep compiling against the same class names.
+//
+// What is mirrored (reference file:line):
+//   PacBio::Data::ArrayBase / ArrayRead        include/pacbio/data/ArrayRead.h:60-119 (boost::optional QVs -> has* flags)
+//   PacBio::Data::QvThresholds                 include/pacbio/data/QvThresholds.h:44-54, src/QvThresholds.cpp:45-56
+//   PacBio::Data::MSAByRow                     include/pacbio/data/MSA.h:59-93   (BeginPos/EndPos 1-based, CodonsAt)
+//   PacBio::Data::MSAByColumn / MSAColumn      include/pacbio/data/MSA.h:115-214 (operator[](abs0), Coverage, Frequency, MaxBase)
+//   PacBio::Statistics::Fisher                 include/pacbio/statistics/Fisher.h:12-25
+//   PacBio::Juliet::ErrorEstimates             include/pacbio/juliet/ErrorEstimates.h:49-61
+//   PacBio::Juliet::TargetGene/DRM/DMutation/ExpectedMinor/TargetConfig (data members only) TargetConfig.h:49-139
+//   PacBio::Juliet::VariantGene                include/pacbio/juliet/VariantGene.h:49-81 (msa context as plain structs)
+//   PacBio::Juliet::AminoAcidCaller            include/pacbio/juliet/AminoAcidCaller.h:90-154 (CallVariants + store policy)
+// Not mirrored in this round: MSAByRow::Rows()/NameToRow (only PhaseVariants needs the per-read rows),
+// per-column insertion maps, JSON serialisation, TargetConfig JSON parsing.
+//
+// Errors: ABI status codes come back as the reference's exceptions -- std::runtime_error("Unexpected cigar ..") /
+// ("Unexpected base ..") (src/MSA.cpp:85,182), std::out_of_range (referenceSequence.substr,
+// src/AminoAcidCaller.cpp:446); anything else (no GPU, HIP failure) is a std::runtime_error carrying
+// msq_last_error().  There is no CPU fallback.
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/msq_abi.h"
+
+namespace PacBio {
+namespace Msq {
+// ---- plumbing: one context per process (the reference is single-threaded)
+inline void Check(int rc)
+{
+    if (rc == MSQ_OK) return;
+    const std::string text = msq_last_error();
+    if (rc == MSQ_ERR_RANGE) throw std::out_of_range(text);
+    throw std::runtime_error(text);
+}
+inline msq_ctx* Context()
+{
+    static msq_ctx* ctx = [] {
+        msq_ctx* c = nullptr;
+        Check(msq_ctx_create(0, &c));
+        return c;
+    }();
+    return ctx;
+}
+template <typename T>
+class DeviceBuffer
+{
+public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t n) : n_(n)
+    {
+        void* p = nullptr;
+        Check(msq_dev_malloc(Context(), std::max<size_t>(n, 1) * sizeof(T), &p));
+        p_ = static_cast<T*>(p);
+        Check(msq_dev_memset(Context(), p_, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    }
+    DeviceBuffer(const DeviceBuffer&) = delete;
+    DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+    ~DeviceBuffer()
+    {
+        if (p_) msq_dev_free(Context(), p_);
+    }
+    T* get() const { return p_; }
+    std::vector<T> ToHost() const
+    {
+        std::vector<T> h(n_);
+        if (n_) Check(msq_memcpy_d2h(Context(), h.data(), p_, n_ * sizeof(T)));
+        return h;
+    }
+
+private:
+    T* p_ = nullptr;
+    size_t n_ = 0;
+};
+inline int CodonIndex(const std::string& s)  // -1 unless a key of AminoAcidTable::FromCodon
+{
+    if (s.size() != 3) return -1;
+    int idx = 0;
+    for (char c : s) {
+        const int t = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+        if (t < 0) return -1;
+        idx = idx * 4 + t;
+    }
+    return idx;
+}
+inline std::string CodonString(int idx)
+{
+    static const char b[] = "ACGT";
+    return std::string{b[(idx >> 4) & 3], b[(idx >> 2) & 3], b[idx & 3]};
+}
+}  // namespace Msq
+
+namespace Juliet {
+// AminoAcidTable::FromCodon (src/AminoAcidTable.cpp:43-54): standard code, stop -> 'X'
+struct AminoAcidTable
+{
+    static char FromCodonIndex(int idx)
+    {
+        static const char* tcag = "FFLLSSSSYYXXCCXWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+        static const int t[4] = {2, 1, 3, 0};
+        return tcag[16 * t[(idx >> 4) & 3] + 4 * t[(idx >> 2) & 3] + t[idx & 3]];
+    }
+    static bool Has(const std::string& codon) { return Msq::CodonIndex(codon) >= 0; }
+    static char At(const std::string& codon)
+    {
+        const int i = Msq::CodonIndex(codon);
+        if (i < 0) throw std::out_of_range("AminoAcidTable::FromCodon.at(" + codon + ")");
+        return FromCodonIndex(i);
+    }
+};
+}  // namespace Juliet
+
+namespace Data {
+// ---------------------------------------------------------------------------------------------- ArrayRead
+struct QvThresholds  // include/pacbio/data/QvThresholds.h:44-54; -1 == boost::none
+{
+    QvThresholds()
+    {
+        msq_qv_thresholds t;
+        const int rc = msq_qv_thresholds_from_env(&t);  // getenv + std::stoi, SUBQV default 42
+        if (rc != MSQ_OK) throw std::invalid_argument(msq_last_error());
+        DelQV = t.del; SubQV = t.sub; InsQV = t.ins; QualQV = t.qual;
+    }
+    int DelQV, SubQV, InsQV, QualQV;
+};
+
+struct ArrayBase  // include/pacbio/data/ArrayRead.h:96-119
+{
+    ArrayBase(char cigar, char nucleotide, uint8_t qualQV, uint8_t subQV, uint8_t delQV, uint8_t insQV)
+        : Cigar(cigar), Nucleotide(nucleotide), HasQualQV(true), HasRichQVs(true), QualQV(qualQV), DelQV(delQV), SubQV(subQV), InsQV(insQV)
+    {
+    }
+    ArrayBase(char cigar, char nucleotide, uint8_t qualQV) : Cigar(cigar), Nucleotide(nucleotide), HasQualQV(true), QualQV(qualQV) {}
+    ArrayBase(char cigar, char nucleotide) : Cigar(cigar), Nucleotide(nucleotide) {}
+    char Cigar;
+    char Nucleotide;
+    bool HasQualQV = false, HasRichQVs = false;
+    uint8_t QualQV = 0, DelQV = 0, SubQV = 0, InsQV = 0;
+};
+
+class ArrayRead  // include/pacbio/data/ArrayRead.h:60-81
+{
+public:
+    ArrayRead(const int idx = -1, const std::string& name = "") : idx_(idx), name_(name) {}
+    ArrayRead(const int idx, const std::string& name, size_t referenceStart, size_t referenceEnd, std::vector<ArrayBase> bases)
+        : bases_(std::move(bases)), idx_(idx), name_(name), referenceStart_(referenceStart), referenceEnd_(referenceEnd)
+    {
+    }
+    virtual ~ArrayRead() = default;
+    int ReferenceStart() const { return static_cast<int>(referenceStart_); }
+    int ReferenceEnd() const { return static_cast<int>(referenceEnd_); }
+    const std::vector<ArrayBase>& Bases() const { return bases_; }
+    const std::string& Name() const { return name_; }
+    virtual std::string SequencingChemistry() const { return ""; }
+
+protected:
+    std::vector<ArrayBase> bases_;
+    const int idx_;
+    const std::string name_;
+    size_t referenceStart_ = 0;
+    size_t referenceEnd_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------- MSA
+class MSAByColumn;
+
+/// MSAByRow: the pileup.  The reads are packed (msq_pack_reads), uploaded, and one msq_pileup builds both count
+/// matrices on the GPU; CodonsAt() and MSAByColumn read them back.
+class MSAByRow  // include/pacbio/data/MSA.h:59-93
+{
+public:
+    MSAByRow() = default;
+    MSAByRow(const std::vector<std::shared_ptr<Data::ArrayRead>>& reads)
+    {
+        std::vector<const ArrayRead*> p;
+        for (const auto& r : reads) p.push_back(r.get());
+        Build(p);
+    }
+    MSAByRow(const std::vector<Data::ArrayRead>& reads)
+    {
+        std::vector<const ArrayRead*> p;
+        for (const auto& r : reads) p.push_back(&r);
+        Build(p);
+    }
+    /// The left-most / right-most position of all reads, 1-based after construction (src/MSA.cpp:107-108).
+    int BeginPos() const { return beginPos_; }
+    int EndPos() const { return endPos_; }
+    int Width() const { return width_; }
+    /// Codon histogram at window column i (src/MSA.cpp:126-136): only observed codons appear, in codon order.
+    std::map<std::string, int> CodonsAt(const int i) const
+    {
+        std::map<std::string, int> codons;
+        if (i < 0 || i >= width_) return codons;
+        for (int k = 0; k < 64; ++k)
+            if (const uint32_t n = codon_[(size_t)i * 64 + k]) codons[Msq::CodonString(k)] = static_cast<int>(n);
+        return codons;
+    }
+    const std::vector<uint32_t>& NucleotideCounts() const { return nuc_; }  // [W][6]
+    const std::vector<uint32_t>& CodonCounts() const { return codon_; }     // [W][64]
+    const uint32_t* DeviceCodonCounts() const { return dCodon_ ? dCodon_->get() : nullptr; }
+    size_t NumReads() const { return numReads_; }
+
+private:
+    void Build(const std::vector<const ArrayRead*>& reads)
+    {
+        const QvThresholds qv;  // member qvThresholds_ of the reference: read from the environment per MSA (MSA.h:82)
+        numReads_ = reads.size();
+        // flat ArrayBase columns
+        std::vector<int32_t> rs, re;
+        std::vector<int64_t> off{0};
+        std::vector<char> cigar, nuc;
+        std::vector<uint8_t> qual, sub, del, ins;
+        bool anyQual = false, anyRich = false;
+        for (const auto* r : reads)
+            for (const auto& b : r->Bases()) {
+                anyQual = anyQual || b.HasQualQV;
+                anyRich = anyRich || b.HasRichQVs;
+            }
+        for (const auto* r : reads) {
+            rs.push_back(r->ReferenceStart());
+            re.push_back(r->ReferenceEnd());
+            for (const auto& b : r->Bases()) {
+                cigar.push_back(b.Cigar);
+                nuc.push_back(b.Nucleotide);
+                // an absent QV always passes (ArrayRead.inl:72-87): 255 passes every threshold
+                if (anyQual) qual.push_back(b.HasQualQV ? b.QualQV : 255);
+                if (anyRich) {
+                    sub.push_back(b.HasRichQVs ? b.SubQV : 255);
+                    del.push_back(b.HasRichQVs ? b.DelQV : 255);
+                    ins.push_back(b.HasRichQVs ? b.InsQV : 255);
+                }
+            }
+            off.push_back(static_cast<int64_t>(cigar.size()));
+        }
+        msq_packed_host* packed = nullptr;
+        int rc = msq_pack_reads(reads.size(), rs.data(), re.data(), off.data(), cigar.data(), nuc.data(),
+                                anyQual ? qual.data() : nullptr, anyRich ? sub.data() : nullptr,
+                                anyRich ? del.data() : nullptr, anyRich ? ins.data() : nullptr, &packed);
+        Msq::Check(rc);  // "Unexpected cigar ..." -> std::runtime_error
+        msq_ctx* ctx = Msq::Context();
+        msq_packed_dev* dev = nullptr;
+        rc = msq_reads_upload(ctx, msq_packed_host_view(packed), &dev);
+        msq_packed_host_free(packed);
+        Msq::Check(rc);
+        try {
+            int32_t b0 = 0, e0 = 0;
+            Msq::Check(msq_window_bounds(ctx, msq_packed_dev_view(dev), &b0, &e0));
+            width_ = reads.empty() ? 0 : e0 - b0;
+            beginPos_ = b0;
+            endPos_ = e0;
+            dNuc_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 6));
+            dCodon_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 64));
+            const msq_qv_thresholds t{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
+            Msq::Check(msq_pileup(ctx, msq_packed_dev_view(dev), &t, b0, width_, dNuc_->get(), dCodon_->get(), MSQ_PILEUP_AUTO));
+            Msq::Check(msq_pileup_check(ctx));  // "Unexpected base ..." -> std::runtime_error
+            nuc_ = dNuc_->ToHost();
+            codon_ = dCodon_->ToHost();
+        } catch (...) {
+            msq_packed_dev_free(ctx, dev);
+            throw;
+        }
+        msq_packed_dev_free(ctx, dev);
+        if (!reads.empty()) {  // ++beginPos_, ++endPos_ (src/MSA.cpp:107-108)
+            ++beginPos_;
+            ++endPos_;
+        } else {
+            beginPos_ = std::numeric_limits<int>::max();  // MSA.h:83-84 defaults, then the same ++ (wraps in the reference: UB)
+            endPos_ = 1;
+        }
+    }
+
+    int beginPos_ = std::numeric_limits<int>::max();
+    int endPos_ = 0;
+    int width_ = 0;
+    size_t numReads_ = 0;
+    std::vector<uint32_t> nuc_, codon_;
+    std::shared_ptr<Msq::DeviceBuffer<uint32_t>> dNuc_, dCodon_;
+};
+
+/// A single MSA column: counts per nucleotide {A, C, G, T, -, N}.
+class MSAColumn  // include/pacbio/data/MSA.h:155-214
+{
+public:
+    MSAColumn(int refPos) : refPos_(refPos) {}
+    static int Tag(char c)  // NucleotideToTag, NucleotideConversion.h:69-88
+    {
+        switch (c) {
+            case 'A': return 0;
+            case 'C': return 1;
+            case 'G': return 2;
+            case 'T': return 3;
+            case '-': return 4;
+            case 'N': return 5;
+            default: return 255;
+        }
+    }
+    int operator[](char c) const { return counts_.at(Tag(c)); }
+    double Frequency(char c) const { return counts_.at(Tag(c)) / static_cast<double>(Coverage()); }
+    explicit operator int() { return Coverage(); }
+    int Coverage() const { return std::accumulate(counts_.cbegin(), counts_.cend(), 0); }  // src/MSA.cpp:221
+    char MaxBase() const  // MSA.inl:68-80: first maximum; an 'N' majority prints as ' '
+    {
+        static const char bases[]{'A', 'C', 'G', 'T', '-'};
+        const int m = static_cast<int>(std::distance(counts_.begin(), std::max_element(counts_.begin(), counts_.end())));
+        return m == 5 ? ' ' : bases[m];
+    }
+    int RefPos() const { return refPos_; }
+
+private:
+    std::array<int, 6> counts_{{0, 0, 0, 0, 0, 0}};
+    int refPos_ = -1;
+    friend class MSAByColumn;
+};
+
+/// MSA by columns; index parameters are in ABSOLUTE 0-based reference space.
+class MSAByColumn  // include/pacbio/data/MSA.h:115-150, src/MSA.cpp:55-92
+{
+    using MsaVec = std::vector<MSAColumn>;
+
+public:
+    MSAByColumn(const MSAByRow& msaRows)
+    {
+        beginPos_ = msaRows.BeginPos() - 1;
+        endPos_ = msaRows.EndPos() - 1;
+        const int size = msaRows.Width();
+        int pos = msaRows.BeginPos();
+        counts.reserve(size);
+        const auto& nuc = msaRows.NucleotideCounts();
+        for (int i = 0; i < size; ++i) {
+            counts.emplace_back(pos++);
+            for (int t = 0; t < 6; ++t) counts.back().counts_[t] = static_cast<int>(nuc[(size_t)i * 6 + t]);
+        }
+    }
+    MSAColumn& operator[](int i) const { return const_cast<MSAColumn&>(counts[i - beginPos_]); }
+    bool has(int i) { return i >= beginPos_ && i < endPos_; }
+    MsaVec::iterator begin() { return counts.begin(); }
+    MsaVec::iterator end() { return counts.end(); }
+    MsaVec::const_iterator begin() const { return counts.begin(); }
+    MsaVec::const_iterator end() const { return counts.end(); }
+    MsaVec::const_iterator cbegin() const { return counts.cbegin(); }
+    MsaVec::const_iterator cend() const { return counts.cend(); }
+    int BeginPos() const { return beginPos_; }
+    int EndPos() const { return endPos_; }
+
+private:
+    MsaVec counts;
+    int beginPos_ = std::numeric_limits<int>::max();
+    int endPos_ = 0;
+};
+}  // namespace Data
+
+namespace Statistics {
+class Fisher  // include/pacbio/statistics/Fisher.h:12-25
+{
+public:
+    static double fisher_exact_tiss(int chi11, int chi12, int chi21, int chi22)
+    {
+        double p = 0;
+        Msq::Check(msq_fisher(Msq::Context(), chi11, chi12, chi21, chi22, &p));
+        return p;
+    }
+};
+}  // namespace Statistics
+
+namespace Juliet {
+struct ErrorEstimates  // include/pacbio/juliet/ErrorEstimates.h:49-61, src/ErrorEstimates.cpp:44-67
+{
+    ErrorEstimates() = default;
+    ErrorEstimates(const std::string& /*chemistry*/)
+    {
+        msq_error_model m;
+        msq_error_model_default(&m);
+        Match = m.match; Substitution = m.substitution; Deletion = m.deletion; Insertion = 0;
+    }
+    ErrorEstimates(const double substitutionRate, const double deletionRate)
+    {
+        msq_error_model m;
+        msq_error_model_from_rates(substitutionRate, deletionRate, &m);
+        Match = m.match; Substitution = m.substitution; Deletion = m.deletion; Insertion = 0;
+    }
+    double Match = -1, Substitution = -1, Deletion = -1, Insertion = -1;
+};
+
+class DMutation  // include/pacbio/juliet/TargetConfig.h:49-62, src/TargetConfig.cpp:51-68
+{
+public:
+    DMutation(char refAA, int pos, char curAA) : refAA(refAA), pos(pos), curAA(curAA) {}
+    bool operator==(const DMutation& a) const
+    {
+        if (a.pos != pos) return false;
+        if (a.curAA != '*' && curAA != '*' && a.curAA != curAA) return false;
+        if (a.refAA != '*' && refAA != '*' && a.refAA != refAA) return false;
+        return true;
+    }
+    char refAA;
+    int pos;
+    char curAA;
+};
+struct DRM { std::string name; std::vector<DMutation> positions; };
+struct ExpectedMinor { int position; std::string aminoacid; std::string codon; };
+struct TargetGene  // TargetConfig.h:95-113; begin/end are 1-based reference coordinates
+{
+    TargetGene() = default;
+    TargetGene(const int begin, const int end, const std::string& name, const std::vector<DRM>& drms,
+               const std::vector<ExpectedMinor>& minors = std::vector<ExpectedMinor>())
+        : begin(begin), end(end), name(name), drms(drms), minors(minors)
+    {
+    }
+    int begin = 0, end = 0;
+    std::string name;
+    std::vector<DRM> drms;
+    std::vector<ExpectedMinor> minors;
+};
+struct TargetConfig  // TargetConfig.h:117-139 (data members; JSON parsing stays with the caller)
+{
+    std::vector<TargetGene> targetGenes;
+    std::string referenceName, referenceSequence, version, dbVersion;
+    size_t NumExpectedMinors() const
+    {
+        size_t n = 0;
+        for (const auto& g : targetGenes) n += g.minors.size();
+        return n;
+    }
+    bool HasExpectedMinors() const { return NumExpectedMinors() > 0; }
+};
+struct JulietSettings  // the fields AminoAcidCaller reads, include/pacbio/juliet/JulietSettings.h:68-82
+{
+    TargetConfig TargetConfigUser;
+    bool DRMOnly = false, Verbose = false, Debug = false;
+    double MinimalPerc = 0.1, MaximalPerc = 100;
+};
+
+struct PerformanceMetrics  // include/pacbio/juliet/AminoAcidCaller.h:55-78
+{
+    PerformanceMetrics(double numberOfTests, double numExpectedMinors) : NumberOfTests(numberOfTests), NumExpectedMinors(numExpectedMinors) {}
+    double TruePositives = 0, FalsePositives = 0, FalseNegative = 0, TrueNegative = 0;
+    double NumberOfTests, NumExpectedMinors;
+    double TruePositiveRate() const { return TruePositives / NumExpectedMinors; }
+    double FalsePositiveRate() const { return FalsePositives / (NumberOfTests - NumExpectedMinors); }
+    double Accuracy() const { return (TruePositives + TrueNegative) / (TruePositives + FalsePositives + FalseNegative + TrueNegative); }
+};
+
+struct VariantGene  // include/pacbio/juliet/VariantGene.h:49-81
+{
+    VariantGene(const std::string& name, const int offset) : geneName(name), geneOffset(offset) {}
+    std::string geneName;
+    int geneOffset;
+    struct MsaCounts  // the JSON object of src/AminoAcidCaller.cpp:549-563 as a plain struct
+    {
+        int rel_pos, abs_pos, A, C, G, T, gap, N;
+        std::string wt;
+    };
+    struct VariantPosition
+    {
+        std::string refCodon, altRefCodon;
+        char refAminoAcid = 0, altRefAminoAcid = 0;
+        std::vector<MsaCounts> msa;
+        int coverage = 0;
+        struct VariantCodon
+        {
+            std::string codon;
+            double frequency, pValue;
+            std::string knownDRM;
+            std::vector<bool> haplotypeHit;
+        };
+        std::map<char, std::vector<VariantCodon>> aminoAcidToCodons;
+        bool IsVariant() const { return !aminoAcidToCodons.empty(); }
+    };
+    std::map<int, std::shared_ptr<VariantPosition>> relPositionToVariant;
+};
+
+/// Given a MSA, target config, and noise model, compute variant amino acids.
+class AminoAcidCaller  // include/pacbio/juliet/AminoAcidCaller.h:90-154
+{
+public:
+    AminoAcidCaller(const std::vector<std::shared_ptr<Data::ArrayRead>>& reads, const ErrorEstimates& error,
+                    const JulietSettings& settings)
+        : msaByRow_(reads)
+        , msaByColumn_(msaByRow_)
+        , error_(error)
+        , targetConfig_(settings.TargetConfigUser)
+        , debug_(settings.Debug)
+        , drmOnly_(settings.DRMOnly)
+        , minimalPerc_(settings.MinimalPerc)
+        , maximalPerc_(settings.MaximalPerc)
+    {
+        CallVariants();
+    }
+    const std::vector<VariantGene>& VariantGenes() const { return variantGenes_; }
+    int NumberOfTests() const { return numberOfTests_; }
+    const PerformanceMetrics& Performance() const { return *pm_; }
+    const Data::MSAByRow& Rows() const { return msaByRow_; }
+
+private:
+    Data::MSAByRow msaByRow_;  // declared (and so constructed) before msaByColumn_, as in AminoAcidCaller.h:130-134
+
+public:
+    Data::MSAByColumn msaByColumn_;  // public in the reference too (AminoAcidCaller.h:134)
+
+private:
+    static constexpr float alpha = 0.01;  // AminoAcidCaller.h:108: a float, compared against doubles
+
+    std::string FindDRMs(const std::string& geneName, const std::vector<TargetGene>& genes, const DMutation curDRM) const
+    {  // src/AminoAcidCaller.cpp:105-124
+        std::string drmSummary;
+        for (const auto& gene : genes) {
+            if (geneName == gene.name) {
+                for (const auto& drms : gene.drms)
+                    if (std::find(drms.positions.cbegin(), drms.positions.cend(), curDRM) != drms.positions.cend()) {
+                        if (!drmSummary.empty()) drmSummary += " + ";
+                        drmSummary += drms.name;
+                    }
+                break;
+            }
+        }
+        return drmSummary;
+    }
+    bool MeasurePerformance(const TargetGene& tg, const std::string& codon, const bool& variableSite, const int& aaPos,
+                            const double& p, PerformanceMetrics* pm)
+    {  // src/AminoAcidCaller.cpp:341-378
+        const char aminoacid = AminoAcidTable::At(codon);
+        bool predictor = false;
+        for (const auto& minor : tg.minors)
+            if (aaPos == minor.position && aminoacid == minor.aminoacid[0] && codon == minor.codon) {
+                predictor = true;
+                break;
+            }
+        if (variableSite) {
+            if (predictor) {
+                if (p < alpha) ++pm->TruePositives; else ++pm->FalseNegative;
+            } else {
+                if (p < alpha) ++pm->FalsePositives; else ++pm->TrueNegative;
+            }
+        } else if (predictor) {
+            if (p < alpha) ++pm->TruePositives; else ++pm->FalseNegative;
+        }
+        return predictor;
+    }
+
+    void CallVariants()  // src/AminoAcidCaller.cpp:397-577: the cell arithmetic runs on the GPU, the store policy here
+    {
+        auto genes = targetConfig_.targetGenes;
+        if (genes.empty()) genes.emplace_back(TargetGene(msaByRow_.BeginPos(), msaByRow_.EndPos(), "Unnamed ORF", {}));
+        msq_ctx* ctx = Msq::Context();
+        std::vector<int32_t> gb, ge;
+        for (const auto& g : genes) {
+            gb.push_back(g.begin);
+            ge.push_back(g.end);
+        }
+        const std::string& ref = targetConfig_.referenceSequence;
+        msq_plan* plan = nullptr;
+        Msq::Check(msq_plan_create(ctx, (int32_t)gb.size(), gb.data(), ge.data(), ref.empty() ? nullptr : ref.data(),
+                                   (int64_t)ref.size(), msaByRow_.BeginPos(), msaByRow_.Width(), &plan));
+        const int64_t P = msq_plan_positions(plan);
+        std::vector<msq_position> positions;
+        std::vector<double> pv;
+        try {
+            Msq::DeviceBuffer<msq_position> dPos((size_t)P);
+            Msq::DeviceBuffer<double> dP((size_t)P * 64), dExp((size_t)P * 64);
+            Msq::DeviceBuffer<int32_t> dTests(1);
+            Msq::Check(msq_lfact_reserve(ctx, 2 * (int64_t)msaByRow_.NumReads() + 2));
+            msq_error_model em{error_.Match, error_.Substitution, error_.Deletion};
+            Msq::Check(msq_call_cells(ctx, plan, msaByRow_.DeviceCodonCounts(), &em, maximalPerc_, dPos.get(), dP.get(),
+                                      dExp.get(), dTests.get()));  // std::out_of_range when a gene leaves the reference
+            Msq::Check(msq_call_check(ctx));
+            positions = dPos.ToHost();
+            pv = dP.ToHost();
+            numberOfTests_ = dTests.ToHost()[0];
+        } catch (...) {
+            msq_plan_destroy(ctx, plan);
+            throw;
+        }
+        msq_plan_destroy(ctx, plan);
+
+        pm_.reset(new PerformanceMetrics(numberOfTests_, targetConfig_.NumExpectedMinors()));
+        const bool hasExpectedMinors = pm_->NumExpectedMinors > 0;
+        const bool hasReference = !ref.empty();
+        const auto& codonCounts = msaByRow_.CodonCounts();
+        size_t k = 0;
+        for (size_t g = 0; g < genes.size(); ++g) {
+            const auto& gene = genes[g];
+            VariantGene curVariantGene(gene.name, gene.begin);
+            for (; k < positions.size() && positions[k].gene == (int32_t)g; ++k) {
+                const msq_position& pos = positions[k];
+                const int i = pos.i, absPos = i - 1, aaPos = pos.aa_pos;
+                curVariantGene.relPositionToVariant.emplace(aaPos, std::make_shared<VariantGene::VariantPosition>());
+                auto& cur = curVariantGene.relPositionToVariant.at(aaPos);
+                if (hasReference && absPos >= 0 && (size_t)absPos <= ref.size()) cur->refCodon = ref.substr(absPos, 3);  // :446
+                if (pos.ref_codon >= 0) {
+                    cur->refCodon = Msq::CodonString(pos.ref_codon);
+                    cur->refAminoAcid = AminoAcidTable::FromCodonIndex(pos.ref_codon);
+                }
+                if (pos.alt_codon >= 0) {
+                    cur->altRefCodon = Msq::CodonString(pos.alt_codon);
+                    cur->altRefAminoAcid = AminoAcidTable::FromCodonIndex(pos.alt_codon);
+                }
+                if (pos.skipped) continue;
+                const int coverage = pos.coverage;
+                for (int c = 0; c < 64; ++c) {
+                    const double p = pv[k * 64 + c];
+                    if (p < 0) continue;  // no cell: count 0, reference codon, alternative reference codon
+                    const std::string codon = Msq::CodonString(c);
+                    const int count = (int)codonCounts[(size_t)pos.win_pos * 64 + c];
+                    const double frequency = 1.0 * count / coverage;  // :491
+                    const bool variableSite = frequency < 0.8;        // :492
+                    const bool predictorSite = MeasurePerformance(gene, codon, variableSite, aaPos, p, pm_.get());
+                    auto StoreVariant = [&]() {  // :499-516
+                        if (debug_ || frequency * 100 >= minimalPerc_) {
+                            const char curAA = AminoAcidTable::FromCodonIndex(c);
+                            VariantGene::VariantPosition::VariantCodon vc;
+                            vc.codon = codon;
+                            vc.frequency = frequency;
+                            vc.pValue = p;
+                            vc.knownDRM = FindDRMs(gene.name, genes, DMutation(cur->refAminoAcid, aaPos, curAA));
+                            cur->aminoAcidToCodons[curAA].push_back(vc);
+                        }
+                    };
+                    if (debug_) {  // :519-539
+                        StoreVariant();
+                    } else if (p < alpha) {
+                        if (drmOnly_) {
+                            if (!FindDRMs(gene.name, genes, DMutation(cur->refAminoAcid, aaPos, AminoAcidTable::FromCodonIndex(c))).empty())
+                                StoreVariant();
+                        } else {
+                            if (predictorSite) StoreVariant();
+                            else if (hasExpectedMinors && variableSite) StoreVariant();
+                            else if (!hasExpectedMinors) StoreVariant();
+                        }
+                    }
+                }
+                if (!cur->aminoAcidToCodons.empty()) {  // :544-566
+                    cur->coverage = coverage;
+                    for (int j = -3; j < 6; ++j) {
+                        if (i + j >= msaByRow_.BeginPos() && i + j < msaByRow_.EndPos()) {
+                            const int abs = absPos + j;
+                            const auto& col = msaByColumn_[abs];
+                            VariantGene::MsaCounts mc{j, abs, col['A'], col['C'], col['G'], col['T'], col['-'], col['N'], ""};
+                            mc.wt = hasReference ? std::string(1, ref.at(abs)) : std::string(1, col.MaxBase());
+                            cur->msa.push_back(mc);
+                        }
+                    }
+                }
+            }
+            variantGenes_.emplace_back(std::move(curVariantGene));
+        }
+    }
+
+    std::vector<VariantGene> variantGenes_;
+    const ErrorEstimates error_;
+    const TargetConfig targetConfig_;
+    const bool debug_, drmOnly_;
+    const double minimalPerc_, maximalPerc_;
+    int numberOfTests_ = 1;
+    std::unique_ptr<PerformanceMetrics> pm_;
+};
+}  // namespace Juliet
+}  // namespace PacBio

@@ -1,0 +1,181 @@
+// front_test.cpp -- drives the C++ front (minorseq_amd/cpp/msq_front.hpp) the way juliet's workflow drives the
+// reference classes (src/tools/JulietWorkflow.cpp:136-165) and dumps everything it computes as text, for
+// tests/test_gpu_cpp_front.py to compare with the oracle.  Also mirrors the reference's one unit test,
+// FisherTest.EquivalentWithR (tests/unit/FisherTest.cpp:49-74): prints fisher_exact_tiss(i,1000,10,1000).
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "../../minorseq_amd/cpp/msq_front.hpp"
+
+using namespace PacBio;
+
+static uint64_t g_state = 0x1234567;
+static uint32_t rnd()
+{
+    g_state = g_state * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(g_state >> 33);
+}
+static double urand() { return rnd() / 2147483648.0; }
+
+static std::vector<std::shared_ptr<Data::ArrayRead>> MakeReads(const std::string& ref, int start0, int n, bool rich)
+{
+    static const char nt[] = "ACGT";
+    std::vector<std::shared_ptr<Data::ArrayRead>> reads;
+    const int W = (int)ref.size();
+    for (int r = 0; r < n; ++r) {
+        int a = 0, b = W;
+        if (r > 0 && urand() < 0.3) {
+            a = (int)(rnd() % (W / 2));
+            b = a + 1 + (int)(rnd() % (W - a));
+        }
+        const bool minor = urand() < 0.08;  // a minor clone: three fixed codon changes
+        std::vector<Data::ArrayBase> bases;
+        auto push = [&](char cg, char c) {
+            const uint8_t q = (uint8_t)(rnd() % 94);
+            if (rich)
+                bases.emplace_back(cg, c, q, (uint8_t)(30 + rnd() % 64), (uint8_t)(rnd() % 94), (uint8_t)(rnd() % 94));
+            else
+                bases.emplace_back(cg, c, q);
+        };
+        for (int c = a; c < b; ++c) {
+            if (c > a && urand() < 0.01) push('I', nt[rnd() % 4]);
+            char truth = ref[c];
+            if (minor && (c == 31 || c == 62 || c == 63 || c == 121)) truth = truth == 'A' ? 'G' : 'A';
+            const double u = urand();
+            if (u < 0.004)
+                push('D', '-');
+            else if (u < 0.006)
+                push('X', truth == 'C' ? 'T' : 'C');
+            else
+                push('=', truth);
+        }
+        std::printf("READ %d %d ", start0 + a, start0 + b);
+        for (const auto& x : bases) std::putchar(x.Cigar);
+        std::putchar(' ');
+        for (const auto& x : bases) std::putchar(x.Nucleotide);
+        for (int k = 0; k < (rich ? 4 : 1); ++k) {
+            std::putchar(' ');
+            for (size_t i = 0; i < bases.size(); ++i) {
+                const auto& x = bases[i];
+                std::printf("%s%d", i ? "," : "", k == 0 ? x.QualQV : k == 1 ? x.SubQV : k == 2 ? x.DelQV : x.InsQV);
+            }
+        }
+        std::putchar('\n');
+        reads.push_back(std::make_shared<Data::ArrayRead>(r, "read/" + std::to_string(r), start0 + a, start0 + b, bases));
+    }
+    return reads;
+}
+
+static std::string Tok(std::string s)  // one token per name in the dump
+{
+    for (auto& c : s)
+        if (c == ' ') c = '_';
+    return s;
+}
+
+static void Dump(const char* name, Juliet::AminoAcidCaller& aac)
+{
+    const auto& rows = aac.Rows();
+    std::printf("CASE %s\nBEGIN %d END %d\n", name, rows.BeginPos(), rows.EndPos());
+    for (const auto& col : aac.msaByColumn_)
+        std::printf("NUC %d %d %d %d %d %d %d COV %d MAX %c\n", col.RefPos(), col['A'], col['C'], col['G'], col['T'], col['-'],
+                    col['N'], col.Coverage(), col.MaxBase() == ' ' ? '_' : col.MaxBase());
+    for (int i = 0; i < rows.Width(); ++i) {
+        const auto codons = rows.CodonsAt(i);
+        if (codons.empty()) continue;
+        std::printf("CODON %d", i);
+        for (const auto& kv : codons) std::printf(" %s:%d", kv.first.c_str(), kv.second);
+        std::putchar('\n');
+    }
+    std::printf("NTESTS %d\n", aac.NumberOfTests());
+    for (const auto& vg : aac.VariantGenes())
+        for (const auto& pv : vg.relPositionToVariant) {
+            const auto& vp = *pv.second;
+            for (const auto& aa : vp.aminoAcidToCodons)
+                for (const auto& vc : aa.second)
+                    std::printf("VAR %s %d %s %c %s %.17g %.17g %s COV %d\n", Tok(vg.geneName).c_str(), pv.first, vp.refCodon.c_str(),
+                                aa.first, vc.codon.c_str(), vc.frequency, vc.pValue, vc.knownDRM.empty() ? "-" : Tok(vc.knownDRM).c_str(),
+                                vp.coverage);
+            for (const auto& m : vp.msa)
+                std::printf("MSA %s %d %d %d %d %d %d %d %d %d %s\n", Tok(vg.geneName).c_str(), pv.first, m.rel_pos, m.abs_pos, m.A, m.C, m.G,
+                            m.T, m.gap, m.N, m.wt == " " ? "_" : m.wt.c_str());
+        }
+    const auto& pm = aac.Performance();
+    std::printf("PERF %g %g %g %g\n", pm.TruePositives, pm.FalsePositives, pm.FalseNegative, pm.TrueNegative);
+}
+
+int main()
+{
+    // FisherTest.EquivalentWithR
+    for (int i = 0; i <= 100; ++i) std::printf("FISHER %d %.17g\n", i, Statistics::Fisher::fisher_exact_tiss(i, 1000, 10, 1000));
+
+    std::string ref;
+    for (int i = 0; i < 180; ++i) ref += "ACGT"[rnd() % 4];
+    const int start0 = 40;
+    std::string full(start0, 'A');  // reference in TargetConfig coordinates: 40 filler bases, then the window
+    full += ref;
+    full += std::string(30, 'C');
+    std::printf("REF %s\n", full.c_str());
+
+    const Juliet::ErrorEstimates error("S/P2-C2");
+    {
+        std::printf("READS plain\n");
+        auto reads = MakeReads(ref, start0, 1500, false);
+        Juliet::JulietSettings s;  // no config: one ORF over the window
+        Juliet::AminoAcidCaller aac(reads, error, s);
+        Dump("noconfig", aac);
+
+        Juliet::JulietSettings c;  // two genes in different frames + reference + DRMs + expected minors
+        Juliet::DRM drm1{"drugA", {Juliet::DMutation('*', 11, '*')}};
+        Juliet::DRM drm2{"drugB", {Juliet::DMutation('*', 11, '*'), Juliet::DMutation('*', 21, '*')}};
+        c.TargetConfigUser.targetGenes.emplace_back(41, 161, "geneA", std::vector<Juliet::DRM>{drm1, drm2});
+        c.TargetConfigUser.targetGenes.emplace_back(102, 230, "geneB", std::vector<Juliet::DRM>{});
+        c.TargetConfigUser.referenceSequence = full;
+        Juliet::AminoAcidCaller aac2(reads, error, c);
+        Dump("config", aac2);
+        c.DRMOnly = true;
+        Juliet::AminoAcidCaller aac3(reads, error, c);
+        Dump("drmonly", aac3);
+        c.DRMOnly = false;
+        c.Debug = true;
+        c.MaximalPerc = 90;
+        Juliet::AminoAcidCaller aac4(reads, error, c);
+        Dump("debug_maxperc90", aac4);
+    }
+    {
+        std::printf("READS rich\n");
+        auto reads = MakeReads(ref, start0, 600, true);
+        Juliet::JulietSettings s;
+        Juliet::AminoAcidCaller aac(reads, error, s);  // SUBQV defaults to 42 (src/QvThresholds.cpp:53)
+        Dump("rich_default_subqv42", aac);
+    }
+    // exceptions keep the reference's types and texts
+    try {
+        std::vector<Data::ArrayRead> bad{Data::ArrayRead(0, "x", 0, 3, {Data::ArrayBase('=', 'A', 9), Data::ArrayBase('N', 'C', 9), Data::ArrayBase('=', 'G', 9)})};
+        Data::MSAByRow m(bad);
+        std::printf("ERR none\n");
+    } catch (const std::runtime_error& e) {
+        std::printf("ERR runtime_error %s\n", e.what());
+    }
+    try {
+        std::vector<Data::ArrayRead> bad{Data::ArrayRead(0, "x", 0, 3, {Data::ArrayBase('=', 'A', 9), Data::ArrayBase('=', 'R', 9), Data::ArrayBase('=', 'G', 9)})};
+        Data::MSAByRow m(bad);
+        std::printf("ERR none\n");
+    } catch (const std::runtime_error& e) {
+        std::printf("ERR runtime_error %s\n", e.what());
+    }
+    try {
+        std::printf("READS out_of_range\n");
+        auto reads = MakeReads(ref.substr(0, 30), start0, 5, false);
+        Juliet::JulietSettings c;
+        c.TargetConfigUser.targetGenes.emplace_back(41, 400, "long", std::vector<Juliet::DRM>{});
+        c.TargetConfigUser.referenceSequence = full.substr(0, 100);
+        Juliet::AminoAcidCaller aac(reads, error, c);
+        std::printf("ERR none\n");
+    } catch (const std::out_of_range& e) {
+        std::printf("ERR out_of_range %s\n", e.what());
+    }
+    return 0;
+}

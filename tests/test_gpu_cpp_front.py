@@ -1,0 +1,176 @@
+"""GPU parity of the C++ front (minorseq_amd/cpp/msq_front.hpp): tests/cpp/front_test drives MSAByRow /
+MSAByColumn / AminoAcidCaller / Fisher exactly as juliet's workflow drives the reference classes and dumps what it
+computed; here the dump is checked against the oracle (counts bit-exact, numberOfTests, stored variants with the
+store policy of src/AminoAcidCaller.cpp:499-539 restated below, p within 1e-9 relative) and against the
+reference's own FisherTest.EquivalentWithR table.  The binary is prebuilt by __graft_entry__.build()."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import orc, pymodel
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(HERE, "cpp", "front_test")
+CODONS = pymodel.CODONS
+ALPHA = float(np.float32(0.01))  # AminoAcidCaller.h:108
+
+
+@pytest.fixture(scope="module")
+def dump():
+    assert os.path.exists(BIN), "tests/cpp/front_test not built: run __graft_entry__.build()"
+    env = dict(os.environ)
+    for k in ("DELQV", "SUBQV", "INSQV", "QUALQV"):
+        env.pop(k, None)
+    out = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = {"fisher": {}, "reads": {}, "cases": {}, "err": [], "ref": None}
+    cur_reads = cur_case = None
+    for line in out.stdout.splitlines():
+        t = line.split(" ")
+        if t[0] == "FISHER":
+            d["fisher"][int(t[1])] = float(t[2])
+        elif t[0] == "REF":
+            d["ref"] = t[1]
+        elif t[0] == "READS":
+            cur_reads = d["reads"].setdefault(t[1], [])
+            reads_name = t[1]
+        elif t[0] == "READ":
+            qs = [[int(x) for x in f.split(",")] for f in t[5:]]
+            cur_reads.append((int(t[1]), int(t[2]), t[3], t[4], qs))
+        elif t[0] == "CASE":
+            cur_case = d["cases"].setdefault(t[1], {"reads": reads_name, "nuc": [], "codon": {}, "var": [], "msa": []})
+        elif t[0] == "BEGIN":
+            cur_case["begin"], cur_case["end"] = int(t[1]), int(t[3])
+        elif t[0] == "NUC":
+            cur_case["nuc"].append([int(x) for x in t[1:8]] + [int(t[9]), t[11]])
+        elif t[0] == "CODON":
+            cur_case["codon"][int(t[1])] = {kv.split(":")[0]: int(kv.split(":")[1]) for kv in t[2:]}
+        elif t[0] == "NTESTS":
+            cur_case["ntests"] = int(t[1])
+        elif t[0] == "VAR":
+            cur_case["var"].append((t[1], int(t[2]), t[3], t[4], t[5], float(t[6]), float(t[7]), " ".join(t[8:-2]), int(t[-1])))
+        elif t[0] == "MSA":
+            cur_case["msa"].append((t[1], int(t[2])) + tuple(int(x) for x in t[3:11]) + (t[11],))
+        elif t[0] == "PERF":
+            cur_case["perf"] = [float(x) for x in t[1:]]
+        elif t[0] == "ERR":
+            d["err"].append(" ".join(t[1:]))
+    return d
+
+
+def to_reads(recs, rich):
+    rows = []
+    for start, end, cig, nuc, qs in recs:
+        if rich:
+            rows.append((start, cig, nuc, qs[0], qs[1], qs[2], qs[3]))
+        else:
+            rows.append((start, cig, nuc, qs[0]))
+    r = cases.make_reads(rows, rich=rich)
+    r["ref_end"] = np.array([x[1] for x in recs], dtype=np.int32)
+    return r
+
+
+def test_fisher_equivalent_with_R(dump):
+    p_r = json.load(open(os.path.join(HERE, "golden", "fisher_R_greater.json")))["p"]
+    for i in range(11, 100):  # the reference's own loop and tolerance (tests/unit/FisherTest.cpp:71-73)
+        assert abs(p_r[i] - dump["fisher"][i]) <= p_r[i] / 1e5
+    for i in range(0, 101):
+        want = orc.fisher(i, 1000, 10, 1000)
+        assert abs(dump["fisher"][i] - want) <= 1e-9 * want
+
+
+GENES = {"noconfig": [], "rich_default_subqv42": [],
+         "config": [("geneA", 41, 161), ("geneB", 102, 230)], "drmonly": [("geneA", 41, 161), ("geneB", 102, 230)],
+         "debug_maxperc90": [("geneA", 41, 161), ("geneB", 102, 230)]}
+
+
+def drm_string(gene, aa_pos):  # the DRM table of tests/cpp/front_test.cpp through FindDRMs (src/AminoAcidCaller.cpp:105-124)
+    if gene != "geneA":
+        return ""
+    return {11: "drugA_+_drugB", 21: "drugB"}.get(aa_pos, "")
+
+
+@pytest.mark.parametrize("case", sorted(GENES))
+def test_caller_matches_oracle(dump, case):
+    c = dump["cases"][case]
+    rich = c["reads"] == "rich"
+    reads = to_reads(dump["reads"][c["reads"]], rich)
+    m = orc.Msa(reads, (-1, -1, 42, -1))  # QvThresholds defaults (src/QvThresholds.cpp:52-55)
+    assert (c["begin"], c["end"]) == (m.begin1, m.end1)
+    nuc = m.nuc_counts()
+    got = np.array([x[1:7] for x in c["nuc"]])
+    assert (got == nuc).all()
+    for k, x in enumerate(c["nuc"]):
+        assert x[0] == m.begin1 + k and x[7] == nuc[k].sum()  # RefPos is 1-based (src/MSA.cpp:60-66)
+        best = int(np.argmax(nuc[k]))
+        assert x[8] == ("_" if best == 5 else "ACGT-"[best])
+    cod = m.codon_counts()
+    for i in range(m.W):
+        want = {CODONS[k]: int(v) for k, v in enumerate(cod[i]) if v}
+        assert c["codon"].get(i, {}) == want, i
+
+    genes = GENES[case]
+    ref = dump["ref"] if genes else ""
+    debug = case == "debug_maxperc90"
+    drm_only = case == "drmonly"
+    max_perc = 90.0 if debug else 100.0
+    pos, cells, nt = m.call([g[1] for g in genes], [g[2] for g in genes], ref, maximal_perc=max_perc)
+    assert c["ntests"] == nt
+    names = [g[0] for g in genes] or ["Unnamed_ORF"]
+    want_vars = []
+    for oc in cells:
+        p = pos[oc.position]
+        gene, aa_pos, coverage = names[p[0]], int(p[2]), int(p[4])
+        aa = orc.lib().orc_amino_acid(oc.codon).decode()
+        store = False
+        if debug:
+            store = True
+        elif oc.p < ALPHA:
+            if drm_only:
+                store = bool(drm_string(gene, aa_pos))
+            else:
+                store = True  # no expected minors configured
+        if store and (debug or oc.frequency * 100 >= 0.1):
+            want_vars.append((gene, aa_pos, CODONS[p[5]], aa, CODONS[oc.codon], oc.frequency, oc.p, drm_string(gene, aa_pos) or "-", coverage))
+    key = lambda v: (names.index(v[0]), v[1], v[3], CODONS.index(v[4]))
+    got_vars = sorted(c["var"], key=key)
+    want_vars = sorted(want_vars, key=key)
+    assert len(got_vars) == len(want_vars), (len(got_vars), len(want_vars))
+    assert len(want_vars) > 0  # every case is built to call something
+    for g, w in zip(got_vars, want_vars):
+        assert g[:5] == w[:5] and g[7] == w[7] and g[8] == w[8], (g, w)
+        assert g[5] == w[5]
+        assert abs(g[6] - w[6]) <= 1e-9 * abs(w[6]) + 1e-300
+    # the 9-column context of every stored position comes from the nucleotide matrix (src/AminoAcidCaller.cpp:544-566)
+    stored = {(v[0], v[1]) for v in got_vars}
+    assert {(x[0], x[1]) for x in c["msa"]} == stored
+    gene_begin = {g[0]: g[1] for g in genes} or {"Unnamed_ORF": m.begin1}
+    for gname, aa_pos, rel, absp, A, C_, G, T, gap, N, wt in c["msa"]:
+        i = gene_begin[gname] + 3 * (aa_pos - 1)
+        assert absp == i - 1 + rel and m.begin1 <= i + rel < m.end1
+        col = absp - (m.begin1 - 1)
+        assert [A, C_, G, T, gap, N] == nuc[col].tolist()
+        if ref:
+            assert wt == ref[absp]
+        else:
+            best = int(np.argmax(nuc[col]))
+            assert wt == ("_" if best == 5 else "ACGT-"[best])
+    assert c["perf"][0] == 0  # no expected minors: nothing can be a true positive
+
+
+def test_minor_clone_is_called(dump):
+    # the planted 8 % clone (columns 31, 62/63, 121 of the window) must surface in the no-config run
+    got = {(v[1], v[4]) for v in dump["cases"]["noconfig"]["var"] if v[5] > 0.03}
+    assert len(got) >= 3
+
+
+def test_exceptions_keep_reference_types(dump):
+    e = dump["err"]
+    assert e[0] == "runtime_error Unexpected cigar 78"   # std::to_string('N'), src/MSA.cpp:182
+    assert e[1] == "runtime_error Unexpected base"       # src/MSA.cpp:85
+    assert e[2].startswith("out_of_range")               # referenceSequence.substr, src/AminoAcidCaller.cpp:446

@@ -1,0 +1,81 @@
+"""The N > 1 path on CPU: two gloo ranks shard a read set, pile their shards up (with the oracle standing in for
+the GPU kernel, which needs a GPU), combine window bounds and count matrices with minorseq_amd.sharding -- the
+same functions bench.py runs over RCCL -- and must reproduce the single-process result bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from minorseq_amd import sharding, synth
+from oracle import orc
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            parts = [sharding.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+            for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def _rank_main(rank, world, port, n_reads, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        wl = synth.workload("hiv_1k", n_reads=n_reads)  # staggered reads: shards see different windows
+        first, count = sharding.shard_range(n_reads, rank, world)
+        reads = wl.host_reads(first, count)
+        b0 = int(reads["ref_start"].min()) if count else 2 ** 31 - 1
+        e0 = int(reads["ref_end"].max()) if count else 0
+        gb0, ge0 = sharding.allreduce_bounds(b0, e0, "cpu")
+        W = ge0 - gb0
+        counts = torch.zeros(W * 70, dtype=torch.int32)
+        if count:
+            # The GPU path piles every shard up inside the GLOBAL window (msq_pileup takes win_begin0 and W).  The
+            # oracle derives its window from its reads, so give the shard one extra read that spans the global
+            # window and consists of a single 'P' op: it moves the bounds (src/MSA.cpp:138-142) and adds nothing.
+            reads = dict(reads)
+            reads["n_reads"] = count + 1
+            reads["ref_start"] = np.append(reads["ref_start"], np.int32(gb0))
+            reads["ref_end"] = np.append(reads["ref_end"], np.int32(ge0))
+            reads["base_off"] = np.append(reads["base_off"], reads["base_off"][-1] + 1)
+            reads["cigar"] = np.append(reads["cigar"], np.uint8(ord("P")))
+            reads["nuc"] = np.append(reads["nuc"], np.uint8(ord("*")))
+            reads["qual"] = np.append(reads["qual"], np.uint8(0))
+            m = orc.Msa(reads)
+            assert (m.begin1 - 1, m.W) == (gb0, W)
+            counts[:W * 6] = torch.from_numpy(m.nuc_counts()).reshape(-1)
+            counts[W * 6:] = torch.from_numpy(m.codon_counts()).reshape(-1)
+        sharding.allreduce_counts(counts)
+        if rank == 0:
+            np.save(out_path, np.concatenate([[gb0, ge0], counts.numpy()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("n_reads", [61, 200])
+def test_two_ranks_equal_one(tmp_path, n_reads):
+    out = str(tmp_path / "r0.npy")
+    mp.spawn(_rank_main, args=(2, _free_port(), n_reads, out), nprocs=2, join=True)
+    got = np.load(out)
+    wl = synth.workload("hiv_1k", n_reads=n_reads)
+    m = orc.Msa(wl.host_reads(0, n_reads))
+    assert (int(got[0]) + 1, int(got[1]) + 1) == (m.begin1, m.end1)
+    W = m.W
+    assert (got[2:2 + W * 6].reshape(W, 6) == m.nuc_counts()).all()
+    assert (got[2 + W * 6:].reshape(W, 64) == m.codon_counts()).all()
