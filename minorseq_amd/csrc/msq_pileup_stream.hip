@@ -4,17 +4,24 @@
 // (src/MSA.cpp:55-92,126-136,144-219); how it computes it is built for gfx950:
 //
 //  * Every WAVE is an autonomous worker that streams whole reads, eight at a time (a "wave batch"), through a
-//    private slice of LDS; there is no workgroup barrier in the steady state, so chunk loads stay in flight
-//    across every phase.  Each packed byte is loaded exactly once, 16 B per lane and plane, coalesced
-//    (1 KiB of bit planes + 2 KiB per QV plane per wave instruction), DEPTH chunks ahead of the decode.
-//  * Phase 1 (read space, lane = one 32-base group): the four input planes become four column-space planes
+//    private slice of LDS; there is no workgroup barrier in the steady state.  The eight reads of a batch are
+//    contiguous in the packed format, so the batch is cut into chunks of 64 groups regardless of read borders:
+//    every lane of every chunk load carries data (16 B of bit planes + 32 B per QV plane, coalesced).  The
+//    chunk loads go through NS statically indexed register slots and are issued unconditionally (clamped
+//    addresses instead of predicates), so the compiler can count them: NS-1 chunks stay in flight behind
+//    `s_waitcnt vmcnt(n)` with n > 0 across every phase.
+//  * Phase 1 (read space, lane = one 32-base group): the input planes become four column-space planes
 //    V (QV-passing ACGT), X ('-' or 'N'), B0, B1 (nucleotide code; for X: B0 = 1 means 'N'); insertions / pads
 //    are squeezed out of the 32-bit lane words (software pext, rare), the lane's column offset is a DPP prefix
-//    sum of popcount(column-consuming ops), and the words are OR-ed at that bit offset into the read's LDS row.
-//  * Phase 2 (column space, lane = 32 columns, the wave's 8 rows): rows are compared against a GUIDE sequence
-//    32 columns per instruction.  Cells that match the guide -- nearly all of them in amplicon data -- are
-//    counted in bit-sliced vertical counters held in registers (Harley-Seal carry-save adders); only
-//    deviating valid bases / codons (sequencing errors, minor variants) cost a global atomic.
+//    sum of popcount(column-consuming ops) plus its read's column base (scalar bookkeeping per read border),
+//    and the words are OR-ed at that bit offset into the read's LDS row (rows keep the four planes of a
+//    32-column word side by side: one 64-bit LDS atomic per plane pair).
+//  * Phase 2 (column space, lane = 32 columns): rows are compared against a GUIDE sequence 32 columns per
+//    instruction.  Cells that match the guide -- nearly all of them in amplicon data -- are counted in
+//    bit-sliced vertical counters held in registers (Harley-Seal carry-save adders); a (row, word) pair that
+//    holds any deviating base / codon is pushed on a small per-wave LDS queue and the queue is drained with
+//    one lane per entry, so the rare atomics do not serialise the wave.  When the last 64-word pass is at
+//    most half full, its lanes split the batch's rows in two halves.
 //  * At the end each workgroup reduces its waves' counters through LDS and stores one partial; a small kernel
 //    folds the partials into the count matrices under each workgroup's guide symbols.
 //
@@ -23,28 +30,31 @@
 #include "msq_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
-constexpr int kLevels = 10;       // bit-sliced counter depth: 1023 reads per wave between flushes
-constexpr int kRows = 8;          // reads per wave batch = one Harley-Seal block
-enum QvMode : int { QV_NONE = 0, QV_QUAL = 1, QV_ANY = 2 };
+constexpr int kLevels = 10;       // bit-sliced counter depth: 1023 reads per wave and launch
+constexpr int kLowLevels = 6;     // levels rippled on every add; the upper ones only when a carry reaches them
+constexpr int kRows = 8;          // reads per wave batch
+constexpr int kMaxBatchesPerWave = ((1 << kLevels) - 1) / kRows;
 
 // Waves per workgroup (one workgroup per CU): 12 = 3 per SIMD where the kernel fits 168 VGPRs, else 8 = 2 per SIMD.
-constexpr int max_waves_of(int qv, int passes) { return (qv == QV_NONE && passes == 1) ? 12 : 8; }
-constexpr int kMaxBatchesPerWave = ((1 << kLevels) - 1) / kRows;
+constexpr int max_waves_of(int np, int passes) { return (np == 0 && passes == 1) ? 12 : 8; }
+// Register slots of the chunk pipeline (NS - 1 chunk loads in flight behind the chunk being decoded).
+constexpr int slots_of(int np) { return np == 0 ? 4 : np == 1 ? 3 : 2; }
 
 struct StreamArgs {
     const int32_t* ref_start;
     const uint64_t* group_off;
     const uint4* bop;
-    const uint4* qv[4];  // qual, del, sub, ins planes (two uint4 per group) or nullptr
-    int32_t thr[4];      // -1 = unset
-    uint64_t n_reads;
-    uint64_t n_batches;  // ceil(n_reads / 8)
+    const uint4* qv[4];  // the QV planes that can mask a base (two uint4 per group), compacted
+    int32_t thr[4];      // their thresholds
+    uint64_t read_lo, read_hi;  // this launch covers reads [read_lo, read_hi)
+    uint64_t n_batches;         // ceil((read_hi - read_lo) / 8)
     int32_t win_begin0, W;
-    int32_t G;           // 32-column groups: ceil(W / 32)
-    int32_t RD;          // dwords per LDS row (>= G + 1, multiple of 4)
+    int32_t G;           // 32-column words: ceil(W / 32)
+    int32_t RD;          // words per LDS row (G + 1)
     uint32_t* nuc;
     uint32_t* codon;
     uint32_t* partials;  // [gridDim.x][NC + 1][G*32]
@@ -56,12 +66,12 @@ __device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int k)  // 
     return __builtin_amdgcn_alignbit(hi, lo, k);
 }
 
-// carry-save adder: (a + b + c) -> sum (weight 1), carry (weight 2)
+// carry-save adder: (a + b + c) -> sum (weight 1), carry (weight 2); two v_bitop3 on gfx950
 __device__ __forceinline__ void csa(uint32_t a, uint32_t b, uint32_t c, uint32_t& sum, uint32_t& carry)
 {
-    const uint32_t u = a ^ b;
-    sum = u ^ c;
-    carry = (a & b) | (u & c);
+    const uint32_t s = a ^ b ^ c;
+    carry = (a & b) | (a & c) | (b & c);
+    sum = s;
 }
 
 // Add eight 32-column bit masks into a bit-sliced counter (cnt[l] holds bit l of each column's count).
@@ -86,22 +96,27 @@ __device__ __forceinline__ void counter_add8(uint32_t (&cnt)[L], const uint32_t 
     }
 }
 
-// Add four 32-column bit masks into a bit-sliced counter.
-template <int L>
-__device__ __forceinline__ void counter_add4(uint32_t (&cnt)[L], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+// Add four 32-column bit masks into levels 0 and 1 of a bit-sliced counter; returns the weight-4 carry.
+__device__ __forceinline__ uint32_t counter_add4(uint32_t (&cnt)[kLevels], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
 {
-    uint32_t ones = cnt[0], twos = cnt[1];
     uint32_t t2a, t2b, carry;
-    csa(ones, x0, x1, ones, t2a);
-    csa(ones, x2, x3, ones, t2b);
-    csa(twos, t2a, t2b, twos, carry);
-    cnt[0] = ones; cnt[1] = twos;
+    csa(cnt[0], x0, x1, cnt[0], t2a);
+    csa(cnt[0], x2, x3, cnt[0], t2b);
+    csa(cnt[1], t2a, t2b, cnt[1], carry);
+    return carry;
+}
+
+// Half-adder chain over levels [FROM, TO): returns the carry out of level TO - 1.
+template <int FROM, int TO>
+__device__ __forceinline__ uint32_t ripple(uint32_t (&cnt)[kLevels], uint32_t carry)
+{
 #pragma unroll
-    for (int l = 2; l < L; ++l) {  // ripple the weight-4 carry upwards
+    for (int l = FROM; l < TO; ++l) {
         const uint32_t c = cnt[l] & carry;
         cnt[l] ^= carry;
         carry = c;
     }
+    return carry;
 }
 
 // bit-sliced compare: 2 * a > b, per column
@@ -163,9 +178,17 @@ __device__ __forceinline__ void squeeze4(uint32_t keep, uint32_t& p0, uint32_t& 
     }
 }
 
-__device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v)
+__device__ __forceinline__ void lds_or64(uint64_t* p, uint64_t v)
 {
     __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Order this wave's LDS traffic between phases (lanes exchange data through LDS; no instructions on gfx9).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts (no LDS traffic).
@@ -181,12 +204,26 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// Per-column majority base over every wave's first batch -> the workgroup's guide words gl[3][RD] (valid,
-// code bit 0, code bit 1).  Runs once per workgroup; kept out of line so its registers do not add to the
-// streaming loop's budget.
-__device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl, int NWV, int PS, int RD, int G, int tid, int T)
+__device__ __forceinline__ uint64_t uni64(uint64_t v)
 {
+    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
+}
+
+// Columns of word cg that can start a codon: 1 <= c <= W-3 (MSARow::CodonAt's i > 0, CodingCodonAt's bound;
+// MSA.cpp:193,207).
+__device__ __forceinline__ uint32_t codon_cols_of(int cg, int G, int W)
+{
+    const int c0 = cg * 32;
+    const int lo = max(1 - c0, 0), hi = min(W - 3 - c0, 31);
+    return (cg < G && lo <= hi) ? (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo) : 0u;
+}
+
+// Per-column majority base over every wave's first batch -> the workgroup's guide words gl[RD][4] (valid,
+// code bit 0, code bit 1, 0).  Runs once per workgroup; kept out of line so its registers do not add to the
+// streaming loop's budget.  Rows are [8][RD][4 planes V X B0 B1], WV dwords per wave.
+__device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl, int NWV, int WV, int RD, int G, int tid, int T)
+{
+    const int ROWB = RD * 4;
     for (int cg = tid; cg < G; cg += T) {
         uint32_t cv[8], c0[8], c1[8];  // 8 levels: up to 255 rows (12 waves x 8 = 96)
 #pragma unroll
@@ -195,10 +232,10 @@ __device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl
             uint32_t xv[kRows], x0[kRows], x1[kRows];
 #pragma unroll
             for (int i = 0; i < kRows; ++i) {
-                const uint32_t* rw = lds + wv * 4 * PS + i * RD + cg;
-                xv[i] = rw[0];
-                x0[i] = rw[2 * PS] & xv[i];  // the X rows reuse B0 for 'N': only valid bases vote
-                x1[i] = rw[3 * PS];
+                const uint4 w = *reinterpret_cast<const uint4*>(lds + wv * WV + i * ROWB + cg * 4);
+                xv[i] = w.x;
+                x0[i] = w.z & w.x;  // the X cells reuse B0 for 'N': only valid bases vote
+                x1[i] = w.w;
             }
             counter_add8(cv, xv);
             counter_add8(c0, x0);
@@ -207,140 +244,173 @@ __device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl
         uint32_t any = 0;
 #pragma unroll
         for (int l = 0; l < 8; ++l) any |= cv[l];
-        gl[cg] = any;
-        gl[RD + cg] = any & sliced_twice_gt(c0, cv);
-        gl[2 * RD + cg] = any & sliced_twice_gt(c1, cv);
+        *reinterpret_cast<uint4*>(gl + cg * 4) = make_uint4(any, any & sliced_twice_gt(c0, cv), any & sliced_twice_gt(c1, cv), 0u);
     }
 }
 
 template <int NP>
-struct ChunkData {
+struct Slot {  // one chunk (64 groups) in flight
     uint4 w;
     uint4 qa[NP ? NP : 1], qb[NP ? NP : 1];
 };
-
-// One chunk (<= 64 groups of one read) travelling through the load pipeline; the fields are wave-uniform.
-struct ChunkMeta {
-    uint32_t bits;    // bit 0 valid (0: the stream has ended), bit 1 first chunk of its read, bits 2-4 read slot
-                      // 0..7 in the wave batch, bits 5.. sequence number of its wave batch
-    int32_t rstart;   // ref_start of the read
-    __device__ uint32_t valid() const { return bits & 1u; }
-    __device__ uint32_t first() const { return bits & 2u; }
-    __device__ uint32_t row() const { return (bits >> 2) & 7u; }
-    __device__ uint32_t bseq() const { return bits >> 5; }
-};
-
-__device__ __forceinline__ uint64_t uni64(uint64_t v)
-{
-    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
-}
 
 // constant address space + uniform index = s_load (the arrays are read-only for the whole launch)
 typedef const uint64_t __attribute__((address_space(4))) * const_u64_ptr;
 typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
 
-// Producer side of one wave's chunk stream: wave batches b = wid, wid + TW, ...; reads r = 8b + i, each cut
-// into chunks of <= 64 groups.  Every field is wave-uniform (kept in SGPRs through readfirstlane); the
-// (group_off, ref_start) entries of the NEXT read are fetched with scalar loads one read ahead, so the stream
-// never waits on a vector load for its own bookkeeping.
-struct ReadStream {
-    const_u64_ptr group_off;
-    const_i32_ptr ref_start;
-    uint64_t n_batches, n_reads, TW;
-    // the read being streamed
-    uint64_t gb, g1;   // next group to load, end group
-    int32_t rs;        // its ref_start
-    uint32_t valid, first, bseq, row;
-    // the prefetched next read
-    uint64_t nb, n_g0, n_g1;
-    int32_t n_rs;
-    uint32_t n_row, n_bseq;
+// Producer side: walks this wave's batches b = wid, wid + TW, ... and yields the group range of the next chunk
+// to load.  Every field is wave-uniform (SGPRs); the next batch's range is fetched one batch ahead.
+struct ChunkProducer {
+    const_u64_ptr go;
+    uint64_t read_lo, read_hi, n_batches, TW;
+    uint64_t b, B0, nB0;
+    uint32_t ng, nng, c, live;
 
-    __device__ __forceinline__ void fetch_next()
+    __device__ __forceinline__ void fetch(uint64_t bb, uint64_t& o0, uint32_t& n)
     {
-        n_g0 = n_g1 = 0;
-        n_rs = 0;
-        if (nb < n_batches) {
-            const uint64_t r = nb * kRows + n_row;
-            if (r < n_reads) {
-                n_g0 = uni64(group_off[r]);
-                n_g1 = uni64(group_off[r + 1]);
-                n_rs = (int32_t)uni((uint32_t)ref_start[r]);
-            }
+        o0 = 0;
+        n = 0;
+        if (bb < n_batches) {
+            const uint64_t r0 = read_lo + bb * kRows;
+            const uint64_t r1 = min(r0 + (uint64_t)kRows, read_hi);
+            o0 = uni64(go[r0]);
+            n = uni((uint32_t)(uni64(go[r1]) - o0));
         }
     }
-    __device__ __forceinline__ void seek()  // move to the next non-empty read of the stream
+    __device__ __forceinline__ void init(const uint64_t* group_off, uint64_t lo, uint64_t hi, uint64_t nb, uint64_t wid, uint64_t tw)
     {
-        while (true) {
-            if (nb >= n_batches) {
-                valid = 0;
-                break;
-            }
-            const uint64_t f0 = n_g0, f1 = n_g1;
-            rs = n_rs;
-            row = n_row;
-            bseq = n_bseq;
-            if (++n_row == (uint32_t)kRows) {
-                n_row = 0;
-                nb = uni64(nb + TW);
-                ++n_bseq;
-            }
-            fetch_next();
-            if (f1 > f0) {
-                gb = f0;
-                g1 = f1;
-                first = 1;
-                break;
-            }
-        }
+        go = (const_u64_ptr)(uintptr_t)group_off;
+        read_lo = lo; read_hi = hi; n_batches = nb;
+        TW = uni64(tw);
+        b = uni64(wid);
+        c = 0;
+        live = b < n_batches ? 1u : 0u;
+        fetch(b, B0, ng);
+        fetch(b + TW, nB0, nng);
     }
-    __device__ __forceinline__ void init(const uint64_t* go, const int32_t* rstart, uint64_t nbatches, uint64_t nreads,
-                                         uint64_t wid, uint64_t total_waves)
+    // after a chunk slot of a live batch has been issued; a batch takes a multiple of `ns` slots (the tail ones
+    // carry no chunk), so that slot k of the register pipeline always holds chunks k, k + ns, ... of a batch
+    __device__ __forceinline__ void advance(uint32_t ns)
     {
-        group_off = (const_u64_ptr)(uintptr_t)go;
-        ref_start = (const_i32_ptr)(uintptr_t)rstart;
-        n_batches = nbatches;
-        n_reads = nreads;
-        TW = uni64(total_waves);
-        gb = g1 = 0;
-        rs = 0;
-        valid = 1;
-        first = 1;
-        bseq = row = 0;
-        nb = uni64(wid);
-        n_row = 0;
-        n_bseq = 0;
-        fetch_next();
-        seek();
+        c = uni(c + 1);
+        const uint32_t nch = max(1u, (ng + 63u) >> 6);
+        if (c >= (nch + ns - 1u) / ns * ns) {
+            b = uni64(b + TW);
+            B0 = nB0;
+            ng = nng;
+            c = 0;
+            live = b < n_batches ? 1u : 0u;
+            fetch(b + TW, nB0, nng);
+        }
     }
 };
 
-template <int QV, int PASSES>
-__global__ __launch_bounds__(max_waves_of(QV, PASSES) * 64) void pileup_kernel(StreamArgs a)
+// Consumer side: the same batch sequence, with what the decode needs per read: the group offsets of the
+// batch's reads relative to its first group (a queue of the 7 inner read borders + the end) and the reads'
+// start columns.  All wave-uniform; the next batch's raw entries are fetched one batch ahead.
+struct BatchConsumer {
+    const_u64_ptr go;
+    const_i32_ptr rs;
+    uint64_t read_lo, read_hi, n_batches, TW, b;
+    int32_t win;
+    uint32_t live;
+    uint32_t bq[7];   // group offsets where reads 1..7 of the batch begin (consumed front first)
+    int32_t rq[7];    // their start columns (ref_start - win_begin0)
+    uint32_t rel8, nchunks, c, row_cur, C;
+    int32_t cb_cur;   // column base of the read being decoded: column = cb_cur + C + lane's exclusive prefix
+    uint64_t ngo[kRows + 1];
+    int32_t nrs[kRows];
+
+    __device__ __forceinline__ void fetch(uint64_t bb)
+    {
+        if (bb < n_batches) {
+            const uint64_t r0 = read_lo + bb * kRows;
+#pragma unroll
+            for (int i = 0; i <= kRows; ++i) ngo[i] = uni64(go[min(r0 + (uint64_t)i, read_hi)]);
+#pragma unroll
+            for (int i = 0; i < kRows; ++i) nrs[i] = (int32_t)uni((uint32_t)rs[min(r0 + (uint64_t)i, read_hi - 1)]);
+        }
+    }
+    __device__ __forceinline__ void begin()  // make the prefetched batch current, prefetch the one after
+    {
+        live = b < n_batches ? 1u : 0u;
+        if (live) {
+#pragma unroll
+            for (int i = 1; i < kRows; ++i) {
+                bq[i - 1] = uni((uint32_t)(ngo[i] - ngo[0]));
+                rq[i - 1] = (int32_t)uni((uint32_t)(nrs[i] - win));
+            }
+            rel8 = uni((uint32_t)(ngo[kRows] - ngo[0]));
+            cb_cur = (int32_t)uni((uint32_t)(nrs[0] - win));
+            nchunks = uni(max(1u, (rel8 + 63u) >> 6));
+            c = 0;
+            row_cur = 0;
+            C = 0;
+        }
+    }
+    // the next batch's raw entries: requested when the current batch's chunks are done (its border queues are
+    // dead by then, so the two sets never hold scalar registers together), back long before next() reads them
+    __device__ __forceinline__ void prefetch_next() { fetch(b + TW); }
+    __device__ __forceinline__ void init(const uint64_t* group_off, const int32_t* ref_start, uint64_t lo, uint64_t hi, uint64_t nb,
+                                         int32_t win_begin0, uint64_t wid, uint64_t tw)
+    {
+        go = (const_u64_ptr)(uintptr_t)group_off;
+        rs = (const_i32_ptr)(uintptr_t)ref_start;
+        read_lo = lo; read_hi = hi; n_batches = nb;
+        win = win_begin0;
+        TW = uni64(tw);
+        b = uni64(wid);
+        fetch(b);
+        begin();
+    }
+    __device__ __forceinline__ void next()
+    {
+        b = uni64(b + TW);
+        begin();
+    }
+    __device__ __forceinline__ void pop_border()
+    {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            bq[k] = bq[k + 1];
+            rq[k] = rq[k + 1];
+        }
+        bq[6] = 0xffffffffu;
+    }
+};
+
+template <int NP, int PASSES>
+__global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(StreamArgs a)
 {
-    constexpr int NP = QV == QV_NONE ? 0 : QV == QV_QUAL ? 1 : 4;  // QV planes looked at
-    constexpr int DEPTH = QV == QV_ANY ? 1 : 3;                    // chunk loads in flight ahead of the decode
-    constexpr bool COUNT_N = QV != QV_NONE;                        // Ns are common only under a QV mask
+    constexpr int NS = slots_of(NP);
+    constexpr bool COUNT_N = NP != 0;  // Ns are common only under a QV mask
     constexpr int NC = COUNT_N ? 4 : 3;
     extern __shared__ __align__(16) uint32_t lds[];
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, NWV = T >> 6;
     const int wave = (int)uni((uint32_t)tid >> 6);   // tell the compiler it is wave-uniform: all stream control is scalar
     const int RD = a.RD, G = a.G, W = a.W;
-    const int PS = kRows * RD;                       // one plane of one wave's rows
-    uint32_t* const wrow = lds + wave * 4 * PS;      // this wave's rows: [4 planes][8 rows][RD]
-    uint32_t* const gl = lds + NWV * 4 * PS;         // the workgroup's guide words [3][RD]
+    const int ROWB = RD * 4;                                  // dwords per row: [RD words][V X B0 B1]
+    const int QW = ((kRows * G * 2 + 15) / 16) * 4;           // dwords of the deviation queue (u16 entries)
+    const int WV = kRows * ROWB + QW;                         // dwords per wave
+    uint32_t* const wrow = lds + wave * WV;                   // this wave's rows
+    uint16_t* const queue = reinterpret_cast<uint16_t*>(wrow + kRows * ROWB);
+    uint32_t* const gl = lds + NWV * WV;                      // the workgroup's guide words [RD][4]
     uint32_t my_err = 0;
 
-    // ---- phase-2 identity: in pass p this lane owns columns [32*cg, 32*cg+32), cg = 64*p + lane
-    uint32_t gv_lo[PASSES], gv_hi[PASSES], g0_lo[PASSES], g0_hi[PASSES], g1_lo[PASSES], g1_hi[PASSES], codon_cols[PASSES];
+    // ---- phase-2 identity: in pass p this lane owns word cgp[p].  The last pass, when at most 32 words wide,
+    // splits the batch's rows between the two halves of the wave (rows rbase .. rbase+3).
+    const bool split = (G - 64 * (PASSES - 1)) <= 32;  // wave-uniform
+    int cgp[PASSES];
+    bool act[PASSES];
+    uint32_t gv_lo[PASSES], gv_hi[PASSES], g0_lo[PASSES], g0_hi[PASSES], g1_lo[PASSES], g1_hi[PASSES], ccols[PASSES];
     uint32_t cnt[PASSES][NC][kLevels];
+    const int rbase = split ? (lane >> 5) * 4 : 0;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
+        cgp[p] = (p == PASSES - 1 && split) ? 64 * p + (lane & 31) : 64 * p + lane;
+        act[p] = cgp[p] < G;
+        ccols[p] = codon_cols_of(cgp[p], G, W);
         gv_lo[p] = gv_hi[p] = g0_lo[p] = g0_hi[p] = g1_lo[p] = g1_hi[p] = 0;
-        // columns that can start a codon: 1 <= c <= W-3 (MSARow::CodonAt's i > 0, CodingCodonAt's bound; MSA.cpp:193,207)
-        const int c0 = (p * 64 + lane) * 32;
-        const int lo = max(1 - c0, 0), hi = min(W - 3 - c0, 31);
-        codon_cols[p] = (p * 64 + lane < G && lo <= hi) ? (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo) : 0u;
 #pragma unroll
         for (int k = 0; k < NC; ++k)
 #pragma unroll
@@ -348,48 +418,39 @@ __global__ __launch_bounds__(max_waves_of(QV, PASSES) * 64) void pileup_kernel(S
     }
 
     auto zero_rows = [&]() {  // MSARow(size): all ' '
-        for (int i = lane * 4; i < 4 * PS; i += 256) *reinterpret_cast<uint4*>(&wrow[i]) = make_uint4(0, 0, 0, 0);
+        for (int i = lane * 4; i < kRows * ROWB; i += 256) *reinterpret_cast<uint4*>(&wrow[i]) = make_uint4(0, 0, 0, 0);
     };
     zero_rows();
-    for (int i = tid; i < 3 * RD; i += T) gl[i] = 0;
+    for (int i = tid; i < 4 * RD; i += T) gl[i] = 0;
 
-    // ---- producer side of the chunk stream (all scalar): see ReadStream
-    ReadStream st;
-    st.init(a.group_off, a.ref_start, a.n_batches, a.n_reads, (uint64_t)blockIdx.x * NWV + wave, (uint64_t)gridDim.x * NWV);
-    auto produce = [&](ChunkMeta& m, ChunkData<NP>& d) {
-        m.bits = uni(st.valid | (st.first << 1) | ((st.row & 7u) << 2) | (st.bseq << 5));
-        m.rstart = st.rs;
-        d.w = make_uint4(0u, 0u, ~0u, ~0u);  // beyond the read: op 3
+    // ---- producer: one unconditional chunk load per call (clamped addresses, no predicate around the loads)
+    ChunkProducer pr;
+    pr.init(a.group_off, a.read_lo, a.read_hi, a.n_batches, (uint64_t)blockIdx.x * NWV + wave, (uint64_t)gridDim.x * NWV);
+    auto issue = [&](Slot<NP>& s) {
+        const bool real = pr.live && 64u * pr.c < pr.ng;  // else: a padding slot, one cache line of group 0
+        const uint64_t base = real ? pr.B0 : 0;
+        const uint32_t last = real ? pr.ng - 1u : 0u;
+        const uint32_t off = real ? 64u * pr.c : 0u;
+        const uint64_t g = base + min(off + (uint32_t)lane, last);
+        s.w = a.bop[g];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) d.qa[k] = d.qb[k] = make_uint4(0, 0, 0, 0);
-        if (st.valid) {
-            const uint32_t ngroups = (uint32_t)min(st.g1 - st.gb, (uint64_t)64);
-            if ((uint32_t)lane < ngroups) {
-                const uint64_t g = st.gb + lane;
-                d.w = a.bop[g];
-#pragma unroll
-                for (int k = 0; k < NP; ++k)
-                    if (a.thr[k] >= 0 && a.qv[k]) {  // wave-uniform
-                        d.qa[k] = a.qv[k][2 * g];
-                        d.qb[k] = a.qv[k][2 * g + 1];
-                    }
-            }
-            st.first = 0;
-            st.gb = uni64(st.gb + 64);
-            if (st.gb >= st.g1) st.seek();
+        for (int k = 0; k < NP; ++k) {
+            s.qa[k] = a.qv[k][2 * g];
+            s.qb[k] = a.qv[k][2 * g + 1];
         }
+        if (pr.live) pr.advance(NS);
     };
 
     // ---- phase 1 for one chunk: read space -> column-space planes in LDS (MSAByRow::AddRead, MSA.cpp:144-186)
-    int col = 0;
-    auto decode = [&](const ChunkMeta& m, const ChunkData<NP>& d) {
-        const uint4 w = d.w;
+    BatchConsumer cs;
+    auto decode = [&](const Slot<NP>& s) {
+        const uint32_t g0 = 64u * cs.c;
+        const uint32_t nvalid = cs.rel8 > g0 ? min(cs.rel8 - g0, 64u) : 0u;
+        const uint4 w = s.w;
         uint32_t pass = ~0u;  // ArrayBase::MeetQVThresholds, ArrayRead.inl:67-87
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
-            if (a.thr[k] >= 0 && a.qv[k]) pass &= qv_pass_mask(d.qa[k], d.qb[k], a.thr[k]);  // wave-uniform
-        if (m.first()) col = m.rstart - a.win_begin0;  // MSA.cpp:148
-        const uint32_t cons = ~w.w;                 // ops 0, 1 consume a column
+        for (int k = 0; k < NP; ++k) pass &= qv_pass_mask(s.qa[k], s.qb[k], a.thr[k]);
+        const uint32_t cons = (uint32_t)lane < nvalid ? ~w.w : 0u;  // ops 0, 1 consume a column
         const uint32_t is_m = cons & ~w.z;          // op 0: '=' / 'X'
         const uint32_t op1 = cons & w.z;            // op 1: '-', literal N, exotic
         if (op1 & w.y) my_err |= DEVERR_EXOTIC;     // exotic codes are the simple kernel's job
@@ -400,168 +461,224 @@ __global__ __launch_bounds__(max_waves_of(QV, PASSES) * 64) void pileup_kernel(S
         uint32_t b1 = w.y & pv;
         const int n = __popc(cons);
         if (cons != (n == 32 ? ~0u : ((1u << n) - 1u))) squeeze4(cons, pv, px, b0, b1);
-        // column of this lane's first base: wave-exclusive prefix sum of n
         const int incl = wave_inclusive_scan(n);
-        const int c0 = col + incl - n;
-        col += __builtin_amdgcn_readlane(incl, 63);
+        const int excl = incl - n;
+        // read borders inside this chunk: lanes from the border on belong to the next read / row
+        uint32_t rowv = cs.row_cur;
+        int32_t cbv = cs.cb_cur;
+        while (cs.bq[0] < g0 + 64u) {  // wave-uniform
+            const uint32_t sl = cs.bq[0] - g0;
+            const uint32_t before = cs.C + (uint32_t)__builtin_amdgcn_readlane(excl, (int)sl);
+            cs.row_cur = uni(cs.row_cur + 1u);
+            cs.cb_cur = (int32_t)uni((uint32_t)cs.rq[0] - before);  // MSA.cpp:148: pos = ReferenceStart - beginPos
+            const bool inr = (uint32_t)lane >= sl;
+            rowv = inr ? cs.row_cur : rowv;
+            cbv = inr ? cs.cb_cur : cbv;
+            cs.pop_border();
+        }
+        const int c0 = cbv + (int32_t)cs.C + excl;  // column of this lane's first base
+        cs.C = uni(cs.C + (uint32_t)__builtin_amdgcn_readlane(incl, 63));
+        cs.c = uni(cs.c + 1u);
         if (n) {
             if (c0 < 0 || c0 + n > W) {
                 my_err |= DEVERR_WINDOW;  // assert(pos >= 0) / write past the row, MSA.cpp:149
             } else {
                 const int sh = c0 & 31;
-                uint32_t* p = wrow + m.row() * RD + (c0 >> 5);
+                uint64_t* p = reinterpret_cast<uint64_t*>(wrow + rowv * ROWB + (c0 >> 5) * 4);
                 const uint64_t sv = (uint64_t)pv << sh, sx = (uint64_t)px << sh, s0 = (uint64_t)b0 << sh,
                                s1 = (uint64_t)b1 << sh;
-                lds_or(p, (uint32_t)sv);
-                lds_or(p + 1, (uint32_t)(sv >> 32));
-                lds_or(p + PS, (uint32_t)sx);
-                lds_or(p + PS + 1, (uint32_t)(sx >> 32));
-                lds_or(p + 2 * PS, (uint32_t)s0);
-                lds_or(p + 2 * PS + 1, (uint32_t)(s0 >> 32));
-                lds_or(p + 3 * PS, (uint32_t)s1);
-                lds_or(p + 3 * PS + 1, (uint32_t)(s1 >> 32));
+                lds_or64(p, (sv & 0xffffffffull) | (sx << 32));
+                lds_or64(p + 1, (s0 & 0xffffffffull) | (s1 << 32));
+                lds_or64(p + 2, (sv >> 32) | (sx & 0xffffffff00000000ull));
+                lds_or64(p + 3, (s0 >> 32) | (s1 & 0xffffffff00000000ull));
             }
         }
     };
 
-    // ---- phase 2 for the wave's 8 rows: column space (MSAByColumn ctor MSA.cpp:55-92 + CodonsAt MSA.cpp:126-136,197-219)
+    // ---- phase 2: column space (MSAByColumn ctor MSA.cpp:55-92 + CodonsAt MSA.cpp:126-136,197-219)
+    uint32_t qn = 0;  // entries on the deviation queue (wave-uniform)
+    // four consecutive rows of one word: match / gap / codon / N masks into levels 0-1 of the counters
+    // (returns the weight-4 carries); (row, word) pairs with deviations go on the queue
+    auto rows4 = [&](const int p, const uint32_t* rp, const uint32_t tag, uint32_t (&carry)[NC]) {
+        uint32_t xm[4], xg[4], xc[4], xn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(rp + i * ROWB);
+            const uint4 hi = *reinterpret_cast<const uint4*>(rp + i * ROWB + 4);
+            // valid base equal to the guide base
+            const uint32_t m_lo = lo.x & gv_lo[p] & ~((lo.z ^ g0_lo[p]) | (lo.w ^ g1_lo[p]));
+            const uint32_t m_hi = hi.x & gv_hi[p] & ~((hi.z ^ g0_hi[p]) | (hi.w ^ g1_hi[p]));
+            // codon at column c = columns c, c+1, c+2
+            const uint32_t cm = m_lo & funnel(m_lo, m_hi, 1) & funnel(m_lo, m_hi, 2) & ccols[p];
+            const uint32_t cv = lo.x & funnel(lo.x, hi.x, 1) & funnel(lo.x, hi.x, 2) & ccols[p];
+            const uint32_t n_lo = lo.y & lo.z;
+            xm[i] = m_lo;
+            xg[i] = lo.y & ~lo.z;
+            xc[i] = cm;
+            xn[i] = n_lo;
+            const uint32_t dev = (lo.x & ~m_lo) | (cv & ~cm) | (COUNT_N ? 0u : n_lo);
+            const bool has = dev != 0;
+            const uint64_t bal = __ballot(has);
+            if (bal) {  // wave-uniform, rare
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, qn));
+                if (has) queue[pos] = (uint16_t)(tag + ((uint32_t)i << 8));
+                qn = uni(qn + (uint32_t)__popcll(bal));
+            }
+        }
+        carry[0] = counter_add4(cnt[p][0], xm[0], xm[1], xm[2], xm[3]);
+        carry[1] = counter_add4(cnt[p][1], xg[0], xg[1], xg[2], xg[3]);
+        carry[2] = counter_add4(cnt[p][2], xc[0], xc[1], xc[2], xc[3]);
+        if (COUNT_N) carry[NC - 1] = counter_add4(cnt[p][NC - 1], xn[0], xn[1], xn[2], xn[3]);
+    };
+    // carries into level FROM of every counter of pass p; the upper levels only when some carry gets there
+    auto ripple_all = [&](const int p, auto from, uint32_t (&carry)[NC]) {
+        constexpr int FROM = decltype(from)::value;
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            carry[k] = ripple<FROM, kLowLevels>(cnt[p][k], carry[k]);
+            any |= carry[k];
+        }
+        if (__ballot(any != 0)) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) (void)ripple<kLowLevels, kLevels>(cnt[p][k], carry[k]);
+        }
+    };
     auto phase2 = [&]() {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int cg = p * 64 + lane;
-            if (cg < G) {
-                const int cbase = cg * 32;
-#pragma unroll 1
-                for (int half = 0; half < kRows; half += 4) {  // rolled: bounds the live registers
-                uint32_t x_match[4], x_gap[4], x_codon[4], x_n[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t* rw = wrow + (half + i) * RD + cg;
-                    const uint32_t v_lo = rw[0], v_hi = rw[1];
-                    const uint32_t xx = rw[PS];
-                    const uint32_t b0_lo = rw[2 * PS], b0_hi = rw[2 * PS + 1];
-                    const uint32_t b1_lo = rw[3 * PS], b1_hi = rw[3 * PS + 1];
-                    // valid base equal to the guide base
-                    const uint32_t m_lo = v_lo & gv_lo[p] & ~((b0_lo ^ g0_lo[p]) | (b1_lo ^ g1_lo[p]));
-                    const uint32_t m_hi = v_hi & gv_hi[p] & ~((b0_hi ^ g0_hi[p]) | (b1_hi ^ g1_hi[p]));
-                    // codon at column c = columns c, c+1, c+2
-                    const uint32_t cm = m_lo & funnel(m_lo, m_hi, 1) & funnel(m_lo, m_hi, 2) & codon_cols[p];
-                    const uint32_t cv = v_lo & funnel(v_lo, v_hi, 1) & funnel(v_lo, v_hi, 2) & codon_cols[p];
-                    const uint32_t n_lo = xx & b0_lo;
-                    x_match[i] = m_lo;
-                    x_gap[i] = xx & ~b0_lo;
-                    x_codon[i] = cm;
-                    x_n[i] = n_lo;
-                    // deviations from the guide: one global atomic each (MSAColumn::IncCounts MSA.inl:66; ++codons[codon])
-                    uint32_t nd = v_lo & ~m_lo;
-                    while (nd) {
-                        const int j = __ffs(nd) - 1;
-                        nd &= nd - 1;
-                        const uint32_t code = ((b0_lo >> j) & 1u) | (((b1_lo >> j) & 1u) << 1);
-                        atomicAdd(&a.nuc[(size_t)(cbase + j) * 6 + code], 1u);
-                    }
-                    if (!COUNT_N) {
-                        uint32_t nn = n_lo;
-                        while (nn) {
-                            const int j = __ffs(nn) - 1;
-                            nn &= nn - 1;
-                            atomicAdd(&a.nuc[(size_t)(cbase + j) * 6 + 5], 1u);
-                        }
-                    }
-                    uint32_t cd = cv & ~cm;
-                    while (cd) {
-                        const int j = __ffs(cd) - 1;
-                        cd &= cd - 1;
-                        const uint32_t t0 = funnel(b0_lo, b0_hi, j) & 7u, t1 = funnel(b1_lo, b1_hi, j) & 7u;
-                        const uint32_t idx = ((t1 & 1u) << 5) | ((t0 & 1u) << 4) | ((t1 & 2u) << 2) | ((t0 & 2u) << 1) |
-                                             ((t1 & 4u) >> 1) | ((t0 & 4u) >> 2);
-                        atomicAdd(&a.codon[(size_t)(cbase + j) * 64 + idx], 1u);
-                    }
+            if (p == PASSES - 1 && split) {
+                if (act[p]) {
+                    uint32_t c4[NC];
+                    rows4(p, wrow + rbase * ROWB + cgp[p] * 4, (uint32_t)cgp[p] | ((uint32_t)rbase << 8), c4);
+                    ripple_all(p, std::integral_constant<int, 2>{}, c4);
                 }
-                counter_add4(cnt[p][0], x_match[0], x_match[1], x_match[2], x_match[3]);
-                counter_add4(cnt[p][1], x_gap[0], x_gap[1], x_gap[2], x_gap[3]);
-                counter_add4(cnt[p][2], x_codon[0], x_codon[1], x_codon[2], x_codon[3]);
-                if (COUNT_N) counter_add4(cnt[p][3], x_n[0], x_n[1], x_n[2], x_n[3]);
+            } else {
+                if (act[p]) {
+                    uint32_t c4a[NC], c4b[NC], c8[NC];
+                    rows4(p, wrow + cgp[p] * 4, (uint32_t)cgp[p], c4a);
+                    rows4(p, wrow + 4 * ROWB + cgp[p] * 4, (uint32_t)cgp[p] | (4u << 8), c4b);
+#pragma unroll
+                    for (int k = 0; k < NC; ++k) csa(cnt[p][k][2], c4a[k], c4b[k], cnt[p][k][2], c8[k]);
+                    ripple_all(p, std::integral_constant<int, 3>{}, c8);
                 }
             }
         }
+    };
+    // the queued (row, word) pairs, one lane each: deviations from the guide cost one global atomic each
+    // (MSAColumn::IncCounts MSA.inl:66; ++codons[codon])
+    auto drain = [&]() {
+        // qn was advanced under phase 2's lane predicates: lane 0 owns a word in every pass and holds the total
+        const uint32_t nq = uni(qn);
+        for (uint32_t e = lane; e < nq; e += 64) {
+            const uint32_t ent = queue[e];
+            const int cg = (int)(ent & 0xffu), row = (int)(ent >> 8);
+            const uint32_t* rp = wrow + row * ROWB + cg * 4;
+            const uint4 lo = *reinterpret_cast<const uint4*>(rp), hi = *reinterpret_cast<const uint4*>(rp + 4);
+            const uint4 gl_lo = *reinterpret_cast<const uint4*>(gl + cg * 4), gl_hi = *reinterpret_cast<const uint4*>(gl + cg * 4 + 4);
+            const uint32_t cc = codon_cols_of(cg, G, W);
+            const uint32_t m_lo = lo.x & gl_lo.x & ~((lo.z ^ gl_lo.y) | (lo.w ^ gl_lo.z));
+            const uint32_t m_hi = hi.x & gl_hi.x & ~((hi.z ^ gl_hi.y) | (hi.w ^ gl_hi.z));
+            const uint32_t cm = m_lo & funnel(m_lo, m_hi, 1) & funnel(m_lo, m_hi, 2) & cc;
+            const uint32_t cv = lo.x & funnel(lo.x, hi.x, 1) & funnel(lo.x, hi.x, 2) & cc;
+            const uint32_t nd = lo.x & ~m_lo, cd = cv & ~cm, nn = COUNT_N ? 0u : (lo.y & lo.z);
+            const int cbase = cg * 32;
+            uint32_t bits = nd | cd | nn;
+            while (bits) {
+                const int j = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const size_t col = (size_t)(cbase + j);
+                if ((nd >> j) & 1u) atomicAdd(&a.nuc[col * 6 + (((lo.z >> j) & 1u) | (((lo.w >> j) & 1u) << 1))], 1u);
+                if ((nn >> j) & 1u) atomicAdd(&a.nuc[col * 6 + 5], 1u);
+                if ((cd >> j) & 1u) {
+                    const uint32_t t0 = funnel(lo.z, hi.z, j) & 7u, t1 = funnel(lo.w, hi.w, j) & 7u;
+                    const uint32_t idx = ((t1 & 1u) << 5) | ((t0 & 1u) << 4) | ((t1 & 2u) << 2) | ((t0 & 2u) << 1) |
+                                         ((t1 & 4u) >> 1) | ((t0 & 4u) >> 2);
+                    atomicAdd(&a.codon[col * 64 + idx], 1u);
+                }
+            }
+        }
+        qn = 0;
     };
 
     // ---- the workgroup's guide = per-column majority base over every wave's first batch
     auto learn_guide = [&]() {
         __syncthreads();  // every wave's first batch is in its rows
-        learn_guide_words(lds, gl, NWV, PS, RD, G, tid, T);
+        learn_guide_words(lds, gl, NWV, WV, RD, G, tid, T);
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int cg = p * 64 + lane;
-            if (cg < G) {
-                gv_lo[p] = gl[cg]; gv_hi[p] = gl[cg + 1];
-                g0_lo[p] = gl[RD + cg]; g0_hi[p] = gl[RD + cg + 1];
-                g1_lo[p] = gl[2 * RD + cg]; g1_hi[p] = gl[2 * RD + cg + 1];
+            if (act[p]) {
+                const uint4 l = *reinterpret_cast<const uint4*>(gl + cgp[p] * 4), h = *reinterpret_cast<const uint4*>(gl + cgp[p] * 4 + 4);
+                gv_lo[p] = l.x; g0_lo[p] = l.y; g1_lo[p] = l.z;
+                gv_hi[p] = h.x; g0_hi[p] = h.y; g1_hi[p] = h.z;
             }
         }
     };
 
-    // ---- the stream: DEPTH chunk loads stay in flight ahead of the chunk being decoded
-    ChunkMeta meta[DEPTH + 1];
-    ChunkData<NP> data[DEPTH + 1];
+    // ---- the stream: slot k holds chunk k, k + NS, ...; a slot is refilled right after its chunk is decoded
+    Slot<NP> sl[NS];
 #pragma unroll
-    for (int q = 0; q <= DEPTH; ++q) produce(meta[q], data[q]);
-    bool guide_ready = false, have_rows = false;
-    uint32_t cur_bseq = 0;
-    while (true) {
-        const ChunkMeta m = meta[0];
-        const ChunkData<NP> d = data[0];
+    for (int q = 0; q < NS; ++q) issue(sl[q]);
+    cs.init(a.group_off, a.ref_start, a.read_lo, a.read_hi, a.n_batches, a.win_begin0, (uint64_t)blockIdx.x * NWV + wave,
+            (uint64_t)gridDim.x * NWV);
+    bool guide_ready = false;
+    while (cs.live) {
+        // the batch's chunks, NS slots per trip in a fixed order: every wait for a slot sees the same NS - 1
+        // younger loads behind it
+        for (uint32_t k = 0; k < cs.nchunks; k += NS) {
 #pragma unroll
-        for (int q = 0; q < DEPTH; ++q) {
-            meta[q] = meta[q + 1];
-            data[q] = data[q + 1];
-        }
-        produce(meta[DEPTH], data[DEPTH]);  // next loads go out before this chunk is decoded
-        if (!m.valid() || m.bseq() != cur_bseq) {  // a wave batch is complete
-            if (!guide_ready) {
-                learn_guide();
-                guide_ready = true;
+            for (int q = 0; q < NS; ++q) {
+                if (cs.c < cs.nchunks) decode(sl[q]);
+                issue(sl[q]);
             }
-            if (have_rows) {
-                phase2();
-                zero_rows();
-                have_rows = false;
-            }
-            if (!m.valid()) break;
-            cur_bseq = m.bseq();
         }
-        decode(m, d);
-        have_rows = true;
+        // the wave batch is complete
+        cs.prefetch_next();
+        wave_sync();
+        if (!guide_ready) {
+            learn_guide();
+            guide_ready = true;
+        }
+        phase2();
+        wave_sync();
+        drain();
+        // gfx9 counts loads and returnless atomics on one vmcnt; with both kinds pending the compiler must
+        // assume out-of-order completion and drains to vmcnt(0) at every later wait.  Retire the atomics
+        // here, once per batch, so the chunk loads of the next batch are waited for by count.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        wave_sync();
+        zero_rows();
+        wave_sync();
+        cs.next();
     }
+    if (!guide_ready) learn_guide();  // a wave without reads still meets the workgroup's barriers
 
     // ---- flush: per column the guide's nucleotide / codon bins (meta), then the bit-sliced counters transposed
     // and reduced over the waves through LDS, stored as this workgroup's partial
     __syncthreads();
     const int cols = G * 32;
     uint32_t* const part = a.partials + (size_t)blockIdx.x * (NC + 1) * cols;
-    auto gbit = [&](int plane, int c) -> uint32_t { return (gl[plane * RD + (c >> 5)] >> (c & 31)) & 1u; };
+    uint32_t* const acc = lds;  // [cols], over the rows (no wave needs them any more)
+    auto gbit = [&](int plane, int c) -> uint32_t { return (gl[(c >> 5) * 4 + plane] >> (c & 31)) & 1u; };
     for (int c = tid; c < cols; c += T) {
         const uint32_t v0 = gbit(0, c), v1 = gbit(0, c + 1), v2 = gbit(0, c + 2);
         const uint32_t k0 = gbit(1, c) | (gbit(2, c) << 1), k1 = gbit(1, c + 1) | (gbit(2, c + 1) << 1),
                        k2 = gbit(1, c + 2) | (gbit(2, c + 2) << 1);
         part[(size_t)NC * cols + c] = k0 | (v0 << 2) | (((k0 << 4) | (k1 << 2) | k2) << 8) | ((v0 & v1 & v2) << 14);
     }
-    uint32_t* const acc = lds;
 #pragma unroll
     for (int k = 0; k < NC; ++k) {
         for (int i = tid; i < cols; i += T) acc[i] = 0;
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int cg = p * 64 + lane;
-            if (cg < G) {
+            if (act[p]) {
                 for (int j = 0; j < 32; ++j) {
                     uint32_t v = 0;
 #pragma unroll
                     for (int l = 0; l < kLevels; ++l) v |= ((cnt[p][k][l] >> j) & 1u) << l;
-                    if (v) atomicAdd(&acc[cg * 32 + j], v);
+                    if (v) atomicAdd(&acc[cgp[p] * 32 + j], v);
                 }
             }
         }
@@ -615,12 +732,12 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const uint32_t* __re
 
 typedef void (*pileup_kernel_fn)(StreamArgs);
 
-pileup_kernel_fn pick_kernel(int mode, int passes)
+pileup_kernel_fn pick_kernel(int np, int passes)
 {
     if (passes == 1) {
-        return mode == QV_NONE ? pileup_kernel<QV_NONE, 1> : mode == QV_QUAL ? pileup_kernel<QV_QUAL, 1> : pileup_kernel<QV_ANY, 1>;
+        return np == 0 ? pileup_kernel<0, 1> : np == 1 ? pileup_kernel<1, 1> : np == 2 ? pileup_kernel<2, 1> : pileup_kernel<4, 1>;
     }
-    return mode == QV_NONE ? pileup_kernel<QV_NONE, 2> : mode == QV_QUAL ? pileup_kernel<QV_QUAL, 2> : pileup_kernel<QV_ANY, 2>;
+    return np == 0 ? pileup_kernel<0, 2> : np == 1 ? pileup_kernel<1, 2> : np == 2 ? pileup_kernel<2, 2> : pileup_kernel<4, 2>;
 }
 
 }  // namespace
@@ -630,71 +747,78 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
 {
     *handled = false;
     if (R.flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
+    if (R.n_groups == 0) return MSQ_OK;
     const int G = (W + 31) / 32;
-    if (G > 128) return MSQ_OK;  // wider windows: simple kernel (column super-tiles are future work)
+    if (G > 128) return MSQ_OK;  // wider windows: simple kernel (column slabs are future work)
     const int passes = G <= 64 ? 1 : 2;
-    const int RD = ((G + 1 + 3) / 4) * 4;
-    const size_t wave_lds = (size_t)4 * kRows * RD * 4;  // rows [4][8][RD] per wave
-    const size_t shared_lds = (size_t)3 * RD * 4 + 64;   // guide [3][RD]
-    // waves per workgroup: as many as fit one CU (LDS, 3 waves per SIMD), one workgroup per CU
-    int mode = QV_NONE;
-    const bool q_on = thr.qual >= 0 && R.qual;
-    const bool rich_on = (thr.del >= 0 && R.delqv) || (thr.sub >= 0 && R.subqv) || (thr.ins >= 0 && R.insqv);
-    if (rich_on) mode = QV_ANY;
-    else if (q_on) mode = QV_QUAL;
-    const int NC = mode == QV_NONE ? 3 : 4;
-    const int max_waves = max_waves_of(mode, passes);
-    int nwv = (int)std::min<size_t>(max_waves, (160 * 1024 - shared_lds - 1024) / wave_lds);
-    if (nwv < 1) return MSQ_OK;
-    const uint64_t n_batches = (R.n_reads + kRows - 1) / kRows;
-    int n_wg = ctx->n_cu;
-    if ((uint64_t)n_wg * nwv > n_batches) {  // small inputs: fewer, thinner workgroups
-        nwv = (int)std::max<uint64_t>(1, std::min<uint64_t>(nwv, (n_batches + ctx->n_cu - 1) / ctx->n_cu));
-        n_wg = (int)((n_batches + nwv - 1) / nwv);
-    }
-    while ((size_t)nwv * wave_lds < (size_t)G * 32 * 4) ++nwv;  // the flush reduces through the rows' LDS
-    if (nwv > max_waves) return MSQ_OK;
-    if ((n_batches + (uint64_t)n_wg * nwv - 1) / ((uint64_t)n_wg * nwv) > (uint64_t)kMaxBatchesPerWave) return MSQ_OK;
-    const int T = nwv * 64;
-    const size_t lds = (size_t)nwv * wave_lds + shared_lds;
+    const int RD = G + 1;
 
-    // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
-    void* s = nullptr;
-    int rc = msq_scratch(ctx, (size_t)n_wg * (NC + 1) * G * 32 * 4, &s);
-    if (rc != MSQ_OK) return rc;
-    uint32_t* d_part = (uint32_t*)s;
-
+    // the QV planes that can mask a base (threshold set and plane present; ArrayRead.inl:67-87), compacted
     StreamArgs a;
+    const uint8_t* planes[4] = {R.qual, R.delqv, R.subqv, R.insqv};
+    const int32_t thrs[4] = {thr.qual, thr.del, thr.sub, thr.ins};
+    int np = 0;
+    for (int k = 0; k < 4; ++k)
+        if (thrs[k] >= 0 && planes[k]) {
+            a.qv[np] = reinterpret_cast<const uint4*>(planes[k]);
+            a.thr[np] = thrs[k];
+            ++np;
+        }
+    const int np_kernel = np == 3 ? 4 : np;
+    for (int k = np; k < 4; ++k) {  // a kernel with more plane slots than planes re-applies the last one (idempotent)
+        a.qv[k] = np ? a.qv[np - 1] : nullptr;
+        a.thr[k] = np ? a.thr[np - 1] : -1;
+    }
+    const int NC = np_kernel == 0 ? 3 : 4;
+
+    const size_t wave_lds = (size_t)kRows * RD * 16 + (size_t)((kRows * G * 2 + 15) / 16) * 16;  // rows + deviation queue
+    const size_t shared_lds = (size_t)RD * 16;                                                    // guide words
+    // waves per workgroup: as many as fit one CU (LDS, 2-3 waves per SIMD), one workgroup per CU
+    const int max_waves = max_waves_of(np_kernel, passes);
+    int nwv = (int)std::min<size_t>(max_waves, (160 * 1024 - shared_lds - 512) / wave_lds);
+    if (nwv < 1) return MSQ_OK;
+    const uint64_t reads_per_launch = (uint64_t)ctx->n_cu * nwv * kMaxBatchesPerWave * kRows;  // counters hold 1023 reads per wave
+
+    pileup_kernel_fn kern = pick_kernel(np_kernel, passes);
     a.ref_start = R.ref_start;
     a.group_off = R.group_off;
     a.bop = reinterpret_cast<const uint4*>(R.bop);
-    a.qv[0] = reinterpret_cast<const uint4*>(R.qual);
-    a.qv[1] = reinterpret_cast<const uint4*>(R.delqv);
-    a.qv[2] = reinterpret_cast<const uint4*>(R.subqv);
-    a.qv[3] = reinterpret_cast<const uint4*>(R.insqv);
-    a.thr[0] = thr.qual; a.thr[1] = thr.del; a.thr[2] = thr.sub; a.thr[3] = thr.ins;
-    a.n_reads = R.n_reads;
-    a.n_batches = n_batches;
     a.win_begin0 = win_begin0;
     a.W = W;
     a.G = G; a.RD = RD;
     a.nuc = d_nuc;
     a.codon = d_codon;
-    a.partials = d_part;
     a.err = ctx->d_err;
 
-    pileup_kernel_fn kern = pick_kernel(mode, passes);
-    if (lds > 48 * 1024)
-        MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     msq_timing_mark_begin(ctx);
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(T), lds, ctx->stream, a);
-    msq_timing_mark_end(ctx);
-    MSQ_HIP(hipGetLastError());
-    const int col_blocks = (W + 63) / 64;
-    const int slices = std::max(1, std::min(n_wg / 8, (2 * ctx->n_cu + col_blocks - 1) / col_blocks));
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(256), 0, ctx->stream, d_part, n_wg, NC, G * 32, W,
-                       d_nuc, d_codon);
-    MSQ_HIP(hipGetLastError());
+    for (uint64_t lo = 0; lo < R.n_reads; lo += reads_per_launch) {
+        const uint64_t hi = std::min<uint64_t>(R.n_reads, lo + reads_per_launch);
+        const uint64_t n_batches = (hi - lo + kRows - 1) / kRows;
+        int w = nwv, n_wg = ctx->n_cu;
+        if ((uint64_t)n_wg * w > n_batches) {  // small inputs: fewer, thinner workgroups
+            w = (int)std::max<uint64_t>(1, std::min<uint64_t>(w, (n_batches + ctx->n_cu - 1) / ctx->n_cu));
+            n_wg = (int)((n_batches + w - 1) / w);
+        }
+        const size_t lds = (size_t)w * wave_lds + shared_lds;
+        // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
+        void* s = nullptr;
+        int rc = msq_scratch(ctx, (size_t)ctx->n_cu * (NC + 1) * G * 32 * 4, &s);
+        if (rc != MSQ_OK) return rc;
+        a.partials = (uint32_t*)s;
+        a.read_lo = lo;
+        a.read_hi = hi;
+        a.n_batches = n_batches;
+        if (lds > 48 * 1024)
+            MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
+        if (hi == R.n_reads) msq_timing_mark_end(ctx);
+        MSQ_HIP(hipGetLastError());
+        const int col_blocks = (W + 63) / 64;
+        const int slices = std::max(1, std::min(n_wg / 8, (2 * ctx->n_cu + col_blocks - 1) / col_blocks));
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(256), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
+                           W, d_nuc, d_codon);
+        MSQ_HIP(hipGetLastError());
+    }
     *handled = true;
     return MSQ_OK;
 }
