@@ -32,6 +32,13 @@
 #include <algorithm>
 #include <type_traits>
 
+// MSQ_EXP: compile-time timing experiments only (make EXTRA=-DMSQ_EXP=n); any non-zero value gives WRONG counts.
+// bit 0 skip the LDS ORs of phase 1, bit 1 skip phase 2 + drain, bit 2 skip the squeeze, bit 3 skip the drain,
+// bit 4 skip zero_rows.  The shipped library is always built with 0.
+#ifndef MSQ_EXP
+#define MSQ_EXP 0
+#endif
+
 namespace {
 
 constexpr int kLevels = 10;       // bit-sliced counter depth: 1023 reads per wave and launch
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         uint32_t b0 = (w.x & (pv | op1)) | masked;  // code bit 0; for X: 1 = 'N' (literal N is op 1 code 1)
         uint32_t b1 = w.y & pv;
         const int n = __popc(cons);
-        if (cons != (n == 32 ? ~0u : ((1u << n) - 1u))) squeeze4(cons, pv, px, b0, b1);
+        if (!(MSQ_EXP & 4) && cons != (n == 32 ? ~0u : ((1u << n) - 1u))) squeeze4(cons, pv, px, b0, b1);
         const int incl = wave_inclusive_scan(n);
         const int excl = incl - n;
         // read borders inside this chunk: lanes from the border on belong to the next read / row
@@ -487,10 +494,14 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
                 uint64_t* p = reinterpret_cast<uint64_t*>(wrow + rowv * ROWB + (c0 >> 5) * 4);
                 const uint64_t sv = (uint64_t)pv << sh, sx = (uint64_t)px << sh, s0 = (uint64_t)b0 << sh,
                                s1 = (uint64_t)b1 << sh;
-                lds_or64(p, (sv & 0xffffffffull) | (sx << 32));
-                lds_or64(p + 1, (s0 & 0xffffffffull) | (s1 << 32));
-                lds_or64(p + 2, (sv >> 32) | (sx & 0xffffffff00000000ull));
-                lds_or64(p + 3, (s0 >> 32) | (s1 & 0xffffffff00000000ull));
+                if (MSQ_EXP & 1) {  // timing experiment: keep the operands alive, leave out the LDS atomics
+                    if (((sv ^ sx ^ s0 ^ s1) + (uint64_t)(rowv * ROWB + (c0 >> 5) * 4)) == 0x123456789abcdef1ull) my_err |= DEVERR_RANGE;
+                } else {
+                    lds_or64(p, (sv & 0xffffffffull) | (sx << 32));
+                    lds_or64(p + 1, (s0 & 0xffffffffull) | (s1 << 32));
+                    lds_or64(p + 2, (sv >> 32) | (sx & 0xffffffff00000000ull));
+                    lds_or64(p + 3, (s0 >> 32) | (s1 & 0xffffffff00000000ull));
+                }
             }
         }
     };
@@ -640,15 +651,16 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             learn_guide();
             guide_ready = true;
         }
-        phase2();
+        if (!(MSQ_EXP & 2)) phase2();
         wave_sync();
-        drain();
+        if (!(MSQ_EXP & (2 | 8))) drain();
+        else qn = 0;
         // gfx9 counts loads and returnless atomics on one vmcnt; with both kinds pending the compiler must
         // assume out-of-order completion and drains to vmcnt(0) at every later wait.  Retire the atomics
         // here, once per batch, so the chunk loads of the next batch are waited for by count.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         wave_sync();
-        zero_rows();
+        if (!(MSQ_EXP & 16)) zero_rows();
         wave_sync();
         cs.next();
     }
