@@ -172,16 +172,15 @@ __device__ __forceinline__ uint32_t qv_pass_mask(const uint4& a, const uint4& b,
 // that hold an insertion or a pad), for four planes at once.
 __device__ __forceinline__ void squeeze4(uint32_t keep, uint32_t& p0, uint32_t& p1, uint32_t& p2, uint32_t& p3)
 {
-    if (keep == 0) return;
-    uint32_t holes = ~keep & (0xffffffffu >> __clz(keep));
+    uint32_t holes = keep ? ~keep & (0xffffffffu >> __clz(keep)) : 0u;
     while (holes) {
         const int j = 31 - __clz(holes);  // highest hole first: lower hole positions stay valid
-        const uint32_t low = (1u << j) - 1u;
+        const uint32_t low = __builtin_amdgcn_ubfe(0xffffffffu, 0u, (uint32_t)j);  // bits below j
         p0 = (p0 & low) | ((p0 >> 1) & ~low);
         p1 = (p1 & low) | ((p1 >> 1) & ~low);
         p2 = (p2 & low) | ((p2 >> 1) & ~low);
         p3 = (p3 & low) | ((p3 >> 1) & ~low);
-        holes &= ~(1u << j);
+        holes &= low;
     }
 }
 
@@ -269,27 +268,28 @@ typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
 // to load.  Every field is wave-uniform (SGPRs); the next batch's range is fetched one batch ahead.
 struct ChunkProducer {
     const_u64_ptr go;
-    uint64_t read_lo, read_hi, n_batches, TW;
-    uint64_t b, B0, nB0;
+    uint64_t read_lo, read_hi;
+    uint32_t n_batches, TW, b;
+    uint64_t B0, nB0;
     uint32_t ng, nng, c, live;
 
-    __device__ __forceinline__ void fetch(uint64_t bb, uint64_t& o0, uint32_t& n)
+    __device__ __forceinline__ void fetch(uint32_t bb, uint64_t& o0, uint32_t& n)
     {
         o0 = 0;
         n = 0;
         if (bb < n_batches) {
-            const uint64_t r0 = read_lo + bb * kRows;
+            const uint64_t r0 = read_lo + (uint64_t)bb * kRows;
             const uint64_t r1 = min(r0 + (uint64_t)kRows, read_hi);
             o0 = uni64(go[r0]);
             n = uni((uint32_t)(uni64(go[r1]) - o0));
         }
     }
-    __device__ __forceinline__ void init(const uint64_t* group_off, uint64_t lo, uint64_t hi, uint64_t nb, uint64_t wid, uint64_t tw)
+    __device__ __forceinline__ void init(const uint64_t* group_off, uint64_t lo, uint64_t hi, uint32_t nb, uint32_t wid, uint32_t tw)
     {
         go = (const_u64_ptr)(uintptr_t)group_off;
         read_lo = lo; read_hi = hi; n_batches = nb;
-        TW = uni64(tw);
-        b = uni64(wid);
+        TW = uni(tw);
+        b = uni(wid);
         c = 0;
         live = b < n_batches ? 1u : 0u;
         fetch(b, B0, ng);
@@ -302,7 +302,7 @@ struct ChunkProducer {
         c = uni(c + 1);
         const uint32_t nch = max(1u, (ng + 63u) >> 6);
         if (c >= (nch + ns - 1u) / ns * ns) {
-            b = uni64(b + TW);
+            b = uni(b + TW);
             B0 = nB0;
             ng = nng;
             c = 0;
@@ -312,77 +312,66 @@ struct ChunkProducer {
     }
 };
 
-// Consumer side: the same batch sequence, with what the decode needs per read: the group offsets of the
-// batch's reads relative to its first group (a queue of the 7 inner read borders + the end) and the reads'
-// start columns.  All wave-uniform; the next batch's raw entries are fetched one batch ahead.
+// Consumer side: the same batch sequence, with what the decode needs per read.  The per-read tables of a batch
+// live in two VGPRs (lane i = read i of the batch): bqv = group offset, relative to the batch's first group,
+// where read i begins (lanes 1..7; every other lane holds ~0), rqv = its start column.  The decode walks the
+// read borders with a scalar cursor (bi, bnext) and v_readlane.  The next batch's raw entries come through two
+// plain vector loads issued when the current batch's chunks are done.
 struct BatchConsumer {
-    const_u64_ptr go;
-    const_i32_ptr rs;
-    uint64_t read_lo, read_hi, n_batches, TW, b;
+    const uint32_t* go32;  // group_off viewed as dwords (a batch spans < 2^32 groups: low dwords suffice)
+    const int32_t* rs;
+    uint64_t read_lo, read_hi;
+    uint32_t n_batches, TW, b;
     int32_t win;
     uint32_t live;
-    uint32_t bq[7];   // group offsets where reads 1..7 of the batch begin (consumed front first)
-    int32_t rq[7];    // their start columns (ref_start - win_begin0)
-    uint32_t rel8, nchunks, c, row_cur, C;
-    int32_t cb_cur;   // column base of the read being decoded: column = cb_cur + C + lane's exclusive prefix
-    uint64_t ngo[kRows + 1];
-    int32_t nrs[kRows];
+    uint32_t bqv;        // VGPR
+    int32_t rqv;         // VGPR
+    uint32_t bi, bnext;  // next border: read index, group offset (~0 when none is left)
+    uint32_t rel8, nchunks, c, rowoff_cur, C;
+    int32_t cb_cur;      // column base of the read being decoded: column = cb_cur + C + lane's exclusive prefix
+    uint32_t n_go;       // VGPR, prefetched: lane i = low dword of group_off[first read + min(i, 8)]
+    int32_t n_rs;        // VGPR, prefetched: lane i = ref_start[first read + min(i, 7)]
 
-    __device__ __forceinline__ void fetch(uint64_t bb)
+    __device__ __forceinline__ void fetch(uint32_t bb, int lane)  // unconditional loads (clamped indices)
     {
-        if (bb < n_batches) {
-            const uint64_t r0 = read_lo + bb * kRows;
-#pragma unroll
-            for (int i = 0; i <= kRows; ++i) ngo[i] = uni64(go[min(r0 + (uint64_t)i, read_hi)]);
-#pragma unroll
-            for (int i = 0; i < kRows; ++i) nrs[i] = (int32_t)uni((uint32_t)rs[min(r0 + (uint64_t)i, read_hi - 1)]);
-        }
+        const uint64_t r0 = read_lo + (uint64_t)min(bb, n_batches - 1u) * kRows;
+        n_go = go32[2 * min(r0 + (uint64_t)min(lane, kRows), read_hi)];
+        n_rs = rs[min(r0 + (uint64_t)min(lane, kRows - 1), read_hi - 1)];
     }
-    __device__ __forceinline__ void begin()  // make the prefetched batch current, prefetch the one after
+    __device__ __forceinline__ void begin(int lane)  // make the prefetched batch current
     {
         live = b < n_batches ? 1u : 0u;
         if (live) {
-#pragma unroll
-            for (int i = 1; i < kRows; ++i) {
-                bq[i - 1] = uni((uint32_t)(ngo[i] - ngo[0]));
-                rq[i - 1] = (int32_t)uni((uint32_t)(nrs[i] - win));
-            }
-            rel8 = uni((uint32_t)(ngo[kRows] - ngo[0]));
-            cb_cur = (int32_t)uni((uint32_t)(nrs[0] - win));
+            const uint32_t rel = n_go - (uint32_t)__builtin_amdgcn_readlane((int)n_go, 0);
+            rel8 = (uint32_t)__builtin_amdgcn_readlane((int)rel, kRows);
+            bqv = (lane >= 1 && lane < kRows) ? rel : 0xffffffffu;
+            rqv = n_rs - win;  // MSA.cpp:148: pos = ReferenceStart - beginPos
+            cb_cur = __builtin_amdgcn_readlane(rqv, 0);
+            bi = 1;
+            bnext = (uint32_t)__builtin_amdgcn_readlane((int)bqv, 1);
             nchunks = uni(max(1u, (rel8 + 63u) >> 6));
             c = 0;
-            row_cur = 0;
+            rowoff_cur = 0;
             C = 0;
         }
     }
-    // the next batch's raw entries: requested when the current batch's chunks are done (its border queues are
-    // dead by then, so the two sets never hold scalar registers together), back long before next() reads them
-    __device__ __forceinline__ void prefetch_next() { fetch(b + TW); }
-    __device__ __forceinline__ void init(const uint64_t* group_off, const int32_t* ref_start, uint64_t lo, uint64_t hi, uint64_t nb,
-                                         int32_t win_begin0, uint64_t wid, uint64_t tw)
+    __device__ __forceinline__ void prefetch_next(int lane) { fetch(b + TW, lane); }
+    __device__ __forceinline__ void init(const uint64_t* group_off, const int32_t* ref_start, uint64_t lo, uint64_t hi, uint32_t nb,
+                                         int32_t win_begin0, uint32_t wid, uint32_t tw, int lane)
     {
-        go = (const_u64_ptr)(uintptr_t)group_off;
-        rs = (const_i32_ptr)(uintptr_t)ref_start;
+        go32 = reinterpret_cast<const uint32_t*>(group_off);
+        rs = ref_start;
         read_lo = lo; read_hi = hi; n_batches = nb;
         win = win_begin0;
-        TW = uni64(tw);
-        b = uni64(wid);
-        fetch(b);
-        begin();
+        TW = uni(tw);
+        b = uni(wid);
+        fetch(b, lane);
+        begin(lane);
     }
-    __device__ __forceinline__ void next()
+    __device__ __forceinline__ void next(int lane)
     {
-        b = uni64(b + TW);
-        begin();
-    }
-    __device__ __forceinline__ void pop_border()
-    {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            bq[k] = bq[k + 1];
-            rq[k] = rq[k + 1];
-        }
-        bq[6] = 0xffffffffu;
+        b = uni(b + TW);
+        begin(lane);
     }
 };
 
@@ -402,7 +391,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     uint32_t* const wrow = lds + wave * WV;                   // this wave's rows
     uint16_t* const queue = reinterpret_cast<uint16_t*>(wrow + kRows * ROWB);
     uint32_t* const gl = lds + NWV * WV;                      // the workgroup's guide words [RD][4]
-    uint32_t my_err = 0;
+    uint32_t my_err = 0, exotic = 0;
 
     // ---- phase-2 identity: in pass p this lane owns word cgp[p].  The last pass, when at most 32 words wide,
     // splits the batch's rows between the two halves of the wave (rows rbase .. rbase+3).
@@ -432,7 +421,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
 
     // ---- producer: one unconditional chunk load per call (clamped addresses, no predicate around the loads)
     ChunkProducer pr;
-    pr.init(a.group_off, a.read_lo, a.read_hi, a.n_batches, (uint64_t)blockIdx.x * NWV + wave, (uint64_t)gridDim.x * NWV);
+    pr.init(a.group_off, a.read_lo, a.read_hi, (uint32_t)a.n_batches, blockIdx.x * NWV + wave, gridDim.x * NWV);
     auto issue = [&](Slot<NP>& s) {
         const bool real = pr.live && 64u * pr.c < pr.ng;  // else: a padding slot, one cache line of group 0
         const uint64_t base = real ? pr.B0 : 0;
@@ -460,28 +449,29 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         const uint32_t cons = (uint32_t)lane < nvalid ? ~w.w : 0u;  // ops 0, 1 consume a column
         const uint32_t is_m = cons & ~w.z;          // op 0: '=' / 'X'
         const uint32_t op1 = cons & w.z;            // op 1: '-', literal N, exotic
-        if (op1 & w.y) my_err |= DEVERR_EXOTIC;     // exotic codes are the simple kernel's job
+        exotic |= op1 & w.y;                        // exotic codes are the simple kernel's job (checked at the end)
         const uint32_t masked = is_m & ~pass;       // row char = 'N'          (MSA.cpp:165-166)
         uint32_t pv = is_m & pass;                  // row char = nucleotide   (MSA.cpp:163-164)
         uint32_t px = op1 | masked;                 // row char = '-' (MSA.cpp:168-171) or 'N'
         uint32_t b0 = (w.x & (pv | op1)) | masked;  // code bit 0; for X: 1 = 'N' (literal N is op 1 code 1)
         uint32_t b1 = w.y & pv;
         const int n = __popc(cons);
-        if (!(MSQ_EXP & 4) && cons != (n == 32 ? ~0u : ((1u << n) - 1u))) squeeze4(cons, pv, px, b0, b1);
+        if (!(MSQ_EXP & 4)) squeeze4(cons, pv, px, b0, b1);
         const int incl = wave_inclusive_scan(n);
         const int excl = incl - n;
         // read borders inside this chunk: lanes from the border on belong to the next read / row
-        uint32_t rowv = cs.row_cur;
+        uint32_t rowoffv = cs.rowoff_cur;
         int32_t cbv = cs.cb_cur;
-        while (cs.bq[0] < g0 + 64u) {  // wave-uniform
-            const uint32_t sl = cs.bq[0] - g0;
+        while (cs.bnext < g0 + 64u) {  // wave-uniform
+            const uint32_t sl = cs.bnext - g0;
             const uint32_t before = cs.C + (uint32_t)__builtin_amdgcn_readlane(excl, (int)sl);
-            cs.row_cur = uni(cs.row_cur + 1u);
-            cs.cb_cur = (int32_t)uni((uint32_t)cs.rq[0] - before);  // MSA.cpp:148: pos = ReferenceStart - beginPos
+            cs.rowoff_cur = uni(cs.rowoff_cur + (uint32_t)ROWB);
+            cs.cb_cur = (int32_t)uni((uint32_t)__builtin_amdgcn_readlane(cs.rqv, (int)cs.bi) - before);
             const bool inr = (uint32_t)lane >= sl;
-            rowv = inr ? cs.row_cur : rowv;
+            rowoffv = inr ? cs.rowoff_cur : rowoffv;
             cbv = inr ? cs.cb_cur : cbv;
-            cs.pop_border();
+            cs.bi = uni(cs.bi + 1u);
+            cs.bnext = uni((uint32_t)__builtin_amdgcn_readlane((int)cs.bqv, (int)cs.bi));  // lane 8 holds ~0: no border left
         }
         const int c0 = cbv + (int32_t)cs.C + excl;  // column of this lane's first base
         cs.C = uni(cs.C + (uint32_t)__builtin_amdgcn_readlane(incl, 63));
@@ -490,17 +480,20 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             if (c0 < 0 || c0 + n > W) {
                 my_err |= DEVERR_WINDOW;  // assert(pos >= 0) / write past the row, MSA.cpp:149
             } else {
-                const int sh = c0 & 31;
-                uint64_t* p = reinterpret_cast<uint64_t*>(wrow + rowv * ROWB + (c0 >> 5) * 4);
-                const uint64_t sv = (uint64_t)pv << sh, sx = (uint64_t)px << sh, s0 = (uint64_t)b0 << sh,
-                               s1 = (uint64_t)b1 << sh;
+                // the lane's words at bit offset sh of word c0 >> 5: low part, and the spill into the next word
+                const int sh = c0 & 31, rs = 31 - sh;
+                uint64_t* p = reinterpret_cast<uint64_t*>(wrow + rowoffv + (c0 >> 5) * 4);
+                const uint64_t lo_vx = (uint64_t)(pv << sh) | ((uint64_t)(px << sh) << 32);
+                const uint64_t lo_b = (uint64_t)(b0 << sh) | ((uint64_t)(b1 << sh) << 32);
+                const uint64_t hi_vx = (uint64_t)((pv >> 1) >> rs) | ((uint64_t)((px >> 1) >> rs) << 32);
+                const uint64_t hi_b = (uint64_t)((b0 >> 1) >> rs) | ((uint64_t)((b1 >> 1) >> rs) << 32);
                 if (MSQ_EXP & 1) {  // timing experiment: keep the operands alive, leave out the LDS atomics
-                    if (((sv ^ sx ^ s0 ^ s1) + (uint64_t)(rowv * ROWB + (c0 >> 5) * 4)) == 0x123456789abcdef1ull) my_err |= DEVERR_RANGE;
+                    if (((lo_vx ^ lo_b ^ hi_vx ^ hi_b) + (uint64_t)(rowoffv + (c0 >> 5) * 4)) == 0x123456789abcdef1ull) my_err |= DEVERR_RANGE;
                 } else {
-                    lds_or64(p, (sv & 0xffffffffull) | (sx << 32));
-                    lds_or64(p + 1, (s0 & 0xffffffffull) | (s1 << 32));
-                    lds_or64(p + 2, (sv >> 32) | (sx & 0xffffffff00000000ull));
-                    lds_or64(p + 3, (s0 >> 32) | (s1 & 0xffffffff00000000ull));
+                    lds_or64(p, lo_vx);
+                    lds_or64(p + 1, lo_b);
+                    lds_or64(p + 2, hi_vx);
+                    lds_or64(p + 3, hi_b);
                 }
             }
         }
@@ -631,8 +624,8 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     Slot<NP> sl[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) issue(sl[q]);
-    cs.init(a.group_off, a.ref_start, a.read_lo, a.read_hi, a.n_batches, a.win_begin0, (uint64_t)blockIdx.x * NWV + wave,
-            (uint64_t)gridDim.x * NWV);
+    cs.init(a.group_off, a.ref_start, a.read_lo, a.read_hi, (uint32_t)a.n_batches, a.win_begin0, blockIdx.x * NWV + wave,
+            gridDim.x * NWV, lane);
     bool guide_ready = false;
     while (cs.live) {
         // the batch's chunks, NS slots per trip in a fixed order: every wait for a slot sees the same NS - 1
@@ -645,7 +638,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             }
         }
         // the wave batch is complete
-        cs.prefetch_next();
+        cs.prefetch_next(lane);
         wave_sync();
         if (!guide_ready) {
             learn_guide();
@@ -662,7 +655,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         wave_sync();
         if (!(MSQ_EXP & 16)) zero_rows();
         wave_sync();
-        cs.next();
+        cs.next(lane);
     }
     if (!guide_ready) learn_guide();  // a wave without reads still meets the workgroup's barriers
 
@@ -698,6 +691,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         for (int i = tid; i < cols; i += T) part[(size_t)k * cols + i] = acc[i];
         __syncthreads();
     }
+    if (exotic) my_err |= DEVERR_EXOTIC;
     if (my_err) atomicOr(a.err, my_err);
 }
 
