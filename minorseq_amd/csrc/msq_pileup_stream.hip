@@ -41,7 +41,7 @@
 
 namespace {
 
-constexpr int kLevels = 10;       // bit-sliced counter depth: 1023 reads per wave and launch
+constexpr int kLevels = 10;       // bit-sliced counter depth: 1023 reads per wave and launch (register arrays are sized for it)
 constexpr int kLowLevels = 6;     // levels rippled on every add; the upper ones only when a carry reaches them
 constexpr int kRows = 8;          // reads per wave batch
 constexpr int kMaxBatchesPerWave = ((1 << kLevels) - 1) / kRows;
@@ -49,7 +49,7 @@ constexpr int kMaxBatchesPerWave = ((1 << kLevels) - 1) / kRows;
 // Waves per workgroup (one workgroup per CU): 12 = 3 per SIMD where the kernel fits 168 VGPRs, else 8 = 2 per SIMD.
 constexpr int max_waves_of(int np, int passes) { return (np == 0 && passes == 1) ? 12 : 8; }
 // Register slots of the chunk pipeline (NS - 1 chunk loads in flight behind the chunk being decoded).
-constexpr int slots_of(int np) { return np == 0 ? 4 : np == 1 ? 3 : 2; }
+constexpr int slots_of(int np, int /*passes*/) { return np == 0 ? 4 : np == 1 ? 3 : 2; }
 
 struct StreamArgs {
     const int32_t* ref_start;
@@ -76,8 +76,8 @@ __device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int k)  // 
 // carry-save adder: (a + b + c) -> sum (weight 1), carry (weight 2); two v_bitop3 on gfx950
 __device__ __forceinline__ void csa(uint32_t a, uint32_t b, uint32_t c, uint32_t& sum, uint32_t& carry)
 {
-    const uint32_t s = a ^ b ^ c;
-    carry = (a & b) | (a & c) | (b & c);
+    const uint32_t s = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // a ^ b ^ c
+    carry = __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8);             // majority(a, b, c)
     sum = s;
 }
 
@@ -101,16 +101,6 @@ __device__ __forceinline__ void counter_add8(uint32_t (&cnt)[L], const uint32_t 
         cnt[l] ^= carry;
         carry = c;
     }
-}
-
-// Add four 32-column bit masks into levels 0 and 1 of a bit-sliced counter; returns the weight-4 carry.
-__device__ __forceinline__ uint32_t counter_add4(uint32_t (&cnt)[kLevels], uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
-{
-    uint32_t t2a, t2b, carry;
-    csa(cnt[0], x0, x1, cnt[0], t2a);
-    csa(cnt[0], x2, x3, cnt[0], t2b);
-    csa(cnt[1], t2a, t2b, cnt[1], carry);
-    return carry;
 }
 
 // Half-adder chain over levels [FROM, TO): returns the carry out of level TO - 1.
@@ -378,7 +368,7 @@ struct BatchConsumer {
 template <int NP, int PASSES>
 __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(StreamArgs a)
 {
-    constexpr int NS = slots_of(NP);
+    constexpr int NS = slots_of(NP, PASSES);
     constexpr bool COUNT_N = NP != 0;  // Ns are common only under a QV mask
     constexpr int NC = COUNT_N ? 4 : 3;
     extern __shared__ __align__(16) uint32_t lds[];
@@ -398,7 +388,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     const bool split = (G - 64 * (PASSES - 1)) <= 32;  // wave-uniform
     int cgp[PASSES];
     bool act[PASSES];
-    uint32_t gv_lo[PASSES], gv_hi[PASSES], g0_lo[PASSES], g0_hi[PASSES], g1_lo[PASSES], g1_hi[PASSES], ccols[PASSES];
+    uint32_t ccols[PASSES];
     uint32_t cnt[PASSES][NC][kLevels];
     const int rbase = split ? (lane >> 5) * 4 : 0;
 #pragma unroll
@@ -406,18 +396,13 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         cgp[p] = (p == PASSES - 1 && split) ? 64 * p + (lane & 31) : 64 * p + lane;
         act[p] = cgp[p] < G;
         ccols[p] = codon_cols_of(cgp[p], G, W);
-        gv_lo[p] = gv_hi[p] = g0_lo[p] = g0_hi[p] = g1_lo[p] = g1_hi[p] = 0;
-#pragma unroll
-        for (int k = 0; k < NC; ++k)
-#pragma unroll
-            for (int l = 0; l < kLevels; ++l) cnt[p][k][l] = 0;
     }
 
     auto zero_rows = [&]() {  // MSARow(size): all ' '
         for (int i = lane * 4; i < kRows * ROWB; i += 256) *reinterpret_cast<uint4*>(&wrow[i]) = make_uint4(0, 0, 0, 0);
     };
     zero_rows();
-    for (int i = tid; i < 4 * RD; i += T) gl[i] = 0;
+    for (int i = tid; i < 4 * (RD + 1); i += T) gl[i] = 0;
 
     // ---- producer: one unconditional chunk load per call (clamped addresses, no predicate around the loads)
     ChunkProducer pr;
@@ -503,23 +488,27 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     uint32_t qn = 0;  // entries on the deviation queue (wave-uniform)
     // four consecutive rows of one word: match / gap / codon / N masks into levels 0-1 of the counters
     // (returns the weight-4 carries); (row, word) pairs with deviations go on the queue
-    auto rows4 = [&](const int p, const uint32_t* rp, const uint32_t tag, uint32_t (&carry)[NC]) {
-        uint32_t xm[4], xg[4], xc[4], xn[4];
+    auto rows4 = [&](const int p, const int wofs, const uint32_t* rp, const uint32_t tag, uint32_t (&carry)[NC]) {
+        uint32_t even[NC], twos[NC];  // streaming Harley-Seal: rows fold in pairs as they come
+        // the guide words of this lane's columns (valid, code bit 0, code bit 1) and of the next word: re-read from
+        // LDS per call, cheaper than twelve more live registers
+        const uint4 ga = *reinterpret_cast<const uint4*>(gl + wofs), gb = *reinterpret_cast<const uint4*>(gl + wofs + 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint4 lo = *reinterpret_cast<const uint4*>(rp + i * ROWB);
             const uint4 hi = *reinterpret_cast<const uint4*>(rp + i * ROWB + 4);
             // valid base equal to the guide base
-            const uint32_t m_lo = lo.x & gv_lo[p] & ~((lo.z ^ g0_lo[p]) | (lo.w ^ g1_lo[p]));
-            const uint32_t m_hi = hi.x & gv_hi[p] & ~((hi.z ^ g0_hi[p]) | (hi.w ^ g1_hi[p]));
+            const uint32_t m_lo = lo.x & ga.x & ~((lo.z ^ ga.y) | (lo.w ^ ga.z));
+            const uint32_t m_hi = hi.x & gb.x & ~((hi.z ^ gb.y) | (hi.w ^ gb.z));
             // codon at column c = columns c, c+1, c+2
             const uint32_t cm = m_lo & funnel(m_lo, m_hi, 1) & funnel(m_lo, m_hi, 2) & ccols[p];
             const uint32_t cv = lo.x & funnel(lo.x, hi.x, 1) & funnel(lo.x, hi.x, 2) & ccols[p];
             const uint32_t n_lo = lo.y & lo.z;
-            xm[i] = m_lo;
-            xg[i] = lo.y & ~lo.z;
-            xc[i] = cm;
-            xn[i] = n_lo;
+            uint32_t x[NC];
+            x[0] = m_lo;
+            x[1] = lo.y & ~lo.z;
+            x[2] = cm;
+            if (COUNT_N) x[NC - 1] = n_lo;
             const uint32_t dev = (lo.x & ~m_lo) | (cv & ~cm) | (COUNT_N ? 0u : n_lo);
             const bool has = dev != 0;
             const uint64_t bal = __ballot(has);
@@ -528,11 +517,19 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
                 if (has) queue[pos] = (uint16_t)(tag + ((uint32_t)i << 8));
                 qn = uni(qn + (uint32_t)__popcll(bal));
             }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (i == 0 || i == 2) {
+                    even[k] = x[k];
+                } else if (i == 1) {
+                    csa(cnt[p][k][0], even[k], x[k], cnt[p][k][0], twos[k]);
+                } else {
+                    uint32_t t2;
+                    csa(cnt[p][k][0], even[k], x[k], cnt[p][k][0], t2);
+                    csa(cnt[p][k][1], twos[k], t2, cnt[p][k][1], carry[k]);
+                }
+            }
         }
-        carry[0] = counter_add4(cnt[p][0], xm[0], xm[1], xm[2], xm[3]);
-        carry[1] = counter_add4(cnt[p][1], xg[0], xg[1], xg[2], xg[3]);
-        carry[2] = counter_add4(cnt[p][2], xc[0], xc[1], xc[2], xc[3]);
-        if (COUNT_N) carry[NC - 1] = counter_add4(cnt[p][NC - 1], xn[0], xn[1], xn[2], xn[3]);
     };
     // carries into level FROM of every counter of pass p; the upper levels only when some carry gets there
     auto ripple_all = [&](const int p, auto from, uint32_t (&carry)[NC]) {
@@ -548,24 +545,23 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             for (int k = 0; k < NC; ++k) (void)ripple<kLowLevels, kLevels>(cnt[p][k], carry[k]);
         }
     };
+    // every lane runs phase 2 (no predicate, so qn and the queue bookkeeping stay scalar): a lane without a word
+    // in a pass reads the all-zero pad word G of its rows and adds nothing
     auto phase2 = [&]() {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
+            const int wofs = (act[p] ? cgp[p] : G) * 4;
             if (p == PASSES - 1 && split) {
-                if (act[p]) {
-                    uint32_t c4[NC];
-                    rows4(p, wrow + rbase * ROWB + cgp[p] * 4, (uint32_t)cgp[p] | ((uint32_t)rbase << 8), c4);
-                    ripple_all(p, std::integral_constant<int, 2>{}, c4);
-                }
+                uint32_t c4[NC];
+                rows4(p, wofs, wrow + rbase * ROWB + wofs, (uint32_t)cgp[p] | ((uint32_t)rbase << 8), c4);
+                ripple_all(p, std::integral_constant<int, 2>{}, c4);
             } else {
-                if (act[p]) {
-                    uint32_t c4a[NC], c4b[NC], c8[NC];
-                    rows4(p, wrow + cgp[p] * 4, (uint32_t)cgp[p], c4a);
-                    rows4(p, wrow + 4 * ROWB + cgp[p] * 4, (uint32_t)cgp[p] | (4u << 8), c4b);
+                uint32_t c4a[NC], c4b[NC], c8[NC];
+                rows4(p, wofs, wrow + wofs, (uint32_t)cgp[p], c4a);
+                rows4(p, wofs, wrow + 4 * ROWB + wofs, (uint32_t)cgp[p] | (4u << 8), c4b);
 #pragma unroll
-                    for (int k = 0; k < NC; ++k) csa(cnt[p][k][2], c4a[k], c4b[k], cnt[p][k][2], c8[k]);
-                    ripple_all(p, std::integral_constant<int, 3>{}, c8);
-                }
+                for (int k = 0; k < NC; ++k) csa(cnt[p][k][2], c4a[k], c4b[k], cnt[p][k][2], c8[k]);
+                ripple_all(p, std::integral_constant<int, 3>{}, c8);
             }
         }
     };
@@ -610,14 +606,6 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         __syncthreads();  // every wave's first batch is in its rows
         learn_guide_words(lds, gl, NWV, WV, RD, G, tid, T);
         __syncthreads();
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            if (act[p]) {
-                const uint4 l = *reinterpret_cast<const uint4*>(gl + cgp[p] * 4), h = *reinterpret_cast<const uint4*>(gl + cgp[p] * 4 + 4);
-                gv_lo[p] = l.x; g0_lo[p] = l.y; g1_lo[p] = l.z;
-                gv_hi[p] = h.x; g0_hi[p] = h.y; g1_hi[p] = h.z;
-            }
-        }
     };
 
     // ---- the stream: slot k holds chunk k, k + NS, ...; a slot is refilled right after its chunk is decoded
@@ -626,10 +614,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     for (int q = 0; q < NS; ++q) issue(sl[q]);
     cs.init(a.group_off, a.ref_start, a.read_lo, a.read_hi, (uint32_t)a.n_batches, a.win_begin0, blockIdx.x * NWV + wave,
             gridDim.x * NWV, lane);
-    bool guide_ready = false;
-    while (cs.live) {
-        // the batch's chunks, NS slots per trip in a fixed order: every wait for a slot sees the same NS - 1
-        // younger loads behind it
+    // the batch's chunks, NS slots per trip in a fixed order: every wait for a slot sees the same NS - 1 younger
+    // loads behind it
+    auto chunks = [&]() {
         for (uint32_t k = 0; k < cs.nchunks; k += NS) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
@@ -637,13 +624,22 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
                 issue(sl[q]);
             }
         }
-        // the wave batch is complete
         cs.prefetch_next(lane);
         wave_sync();
-        if (!guide_ready) {
-            learn_guide();
-            guide_ready = true;
-        }
+    };
+    // The first batch goes into the rows before the guide exists; the guide is learnt from it (the only call and
+    // the only workgroup barriers before the flush: a wave without reads meets them too), and only then do the
+    // counters come to life, so nothing but the load slots is live across the call.
+    bool have = cs.live;
+    if (have) chunks();
+    learn_guide();
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p)
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+#pragma unroll
+            for (int l = 0; l < kLevels; ++l) cnt[p][k][l] = 0;
+    while (have) {  // a wave batch is complete in the rows
         if (!(MSQ_EXP & 2)) phase2();
         wave_sync();
         if (!(MSQ_EXP & (2 | 8))) drain();
@@ -656,8 +652,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         if (!(MSQ_EXP & 16)) zero_rows();
         wave_sync();
         cs.next(lane);
+        have = cs.live;
+        if (have) chunks();
     }
-    if (!guide_ready) learn_guide();  // a wave without reads still meets the workgroup's barriers
 
     // ---- flush: per column the guide's nucleotide / codon bins (meta), then the bit-sliced counters transposed
     // and reduced over the waves through LDS, stored as this workgroup's partial
@@ -778,7 +775,7 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
     const int NC = np_kernel == 0 ? 3 : 4;
 
     const size_t wave_lds = (size_t)kRows * RD * 16 + (size_t)((kRows * G * 2 + 15) / 16) * 16;  // rows + deviation queue
-    const size_t shared_lds = (size_t)RD * 16;                                                    // guide words
+    const size_t shared_lds = (size_t)(RD + 1) * 16;                                                    // guide words
     // waves per workgroup: as many as fit one CU (LDS, 2-3 waves per SIMD), one workgroup per CU
     const int max_waves = max_waves_of(np_kernel, passes);
     int nwv = (int)std::min<size_t>(max_waves, (160 * 1024 - shared_lds - 512) / wave_lds);
