@@ -56,7 +56,12 @@ int msq_memcpy_d2h(msq_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); 
  *
  * A read is a run of 32-base GROUPS; reads start on a group boundary.  Group g holds four 32-bit planes
  * bop[4g..4g+3] = {nucleotide bit0, nucleotide bit1, op bit0, op bit1}; bit k of each plane belongs to
- * base k of the group (genomic order, inserted bases included):
+ * slot k of the group.  Group i of a read holds bases 32i .. 32i+31 of the read (genomic order, inserted bases
+ * included); inside the group either base j sits in slot j (plain layout), or -- MSQ_READS_NORMALIZED, what
+ * msq_pack_reads and the synthetic generator write -- the column-consuming bases (ops 0, 1) fill the slots from
+ * 0 upwards in genomic order and the others (ops 2, 3) fill them from 31 downwards in genomic order, padding
+ * in between.  Nothing on the path looks at where inside its group an inserted or padded base sits
+ * (MSA.cpp:172-180), so the counts are the same; the pileup kernel then needs no bit compaction per group.
  *     nucleotide code  A=0 C=1 G=2 T=3                  (NucleotideConversion.h:69-88 order)
  *     op 0  '=' / 'X'   column-consuming, nucleotide subject to the QV mask   (MSA.cpp:160-167)
  *     op 1  column-consuming symbol that is not a QV-checked ACGT; the nucleotide code selects it:
@@ -89,6 +94,7 @@ typedef struct msq_packed_reads {
 } msq_packed_reads;
 
 #define MSQ_READS_HAS_EXOTIC 1u /* some base uses op 1 with nucleotide code 2 or 3 */
+#define MSQ_READS_NORMALIZED 2u /* inside every group the column-consuming bases come first (see above) */
 
 /* QvThresholds (include/pacbio/data/QvThresholds.h:44-54, src/QvThresholds.cpp:45-56): -1 = boost::none. */
 typedef struct msq_qv_thresholds {

@@ -14,6 +14,7 @@ MSQ_ERR_ARG, MSQ_ERR_HIP, MSQ_ERR_CIGAR, MSQ_ERR_BASE = -1, -2, -3, -4
 MSQ_ERR_WINDOW, MSQ_ERR_RANGE, MSQ_ERR_NODEVICE, MSQ_ERR_NOMEM = -5, -6, -7, -8
 MSQ_PILEUP_AUTO, MSQ_PILEUP_SIMPLE, MSQ_PILEUP_STREAM = 0, 1, 2
 MSQ_READS_HAS_EXOTIC = 1
+MSQ_READS_NORMALIZED = 2
 
 
 class MsqError(RuntimeError):

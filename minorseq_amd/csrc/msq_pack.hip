@@ -84,28 +84,38 @@ extern "C" int msq_pack_reads(uint64_t n_reads, const int32_t* ref_start, const 
             const int64_t b0 = base_off[r], len = base_off[r + 1] - b0;
             const uint64_t g0 = p->group_off[r], ng = p->group_off[r + 1] - g0;
             for (uint64_t gi = 0; gi < ng; ++gi) {
+                // normalized layout (MSQ_READS_NORMALIZED): consuming bases from slot 0 up, the others from 31 down
                 uint32_t n0 = 0, n1 = 0, o0 = 0, o1 = 0;
+                int up = 0, down = 31, slot[32];
                 for (int k = 0; k < 32; ++k) {
                     const int64_t i = (int64_t)gi * 32 + k;
-                    unsigned op = 3, code = 0;  // padding after the last base: consumes nothing
-                    if (i < len && !encode_base(cigar[b0 + i], nuc[b0 + i], &op, &code, &exotic)) {
+                    slot[k] = -1;
+                    if (i >= len) break;
+                    unsigned op = 3, code = 0;
+                    if (!encode_base(cigar[b0 + i], nuc[b0 + i], &op, &code, &exotic)) {
                         const int bad = (unsigned char)cigar[b0 + i];
                         delete p;
                         // std::runtime_error("Unexpected cigar " + std::to_string(b.Cigar)), src/MSA.cpp:182
                         return msq_fail(MSQ_ERR_CIGAR, "Unexpected cigar %d", bad);
                     }
-                    n0 |= (uint32_t)(code & 1) << k;
-                    n1 |= (uint32_t)((code >> 1) & 1) << k;
-                    o0 |= (uint32_t)(op & 1) << k;
-                    o1 |= (uint32_t)((op >> 1) & 1) << k;
+                    const int s = op < 2 ? up++ : down--;
+                    slot[k] = s;
+                    n0 |= (uint32_t)(code & 1) << s;
+                    n1 |= (uint32_t)((code >> 1) & 1) << s;
+                    o0 |= (uint32_t)(op & 1) << s;
+                    o1 |= (uint32_t)((op >> 1) & 1) << s;
+                }
+                for (int s = up; s <= down; ++s) {  // padding between the two runs: op 3, consumes nothing
+                    o0 |= 1u << s;
+                    o1 |= 1u << s;
                 }
                 uint32_t* w = &p->bop[(g0 + gi) * 4];
                 w[0] = n0; w[1] = n1; w[2] = o0; w[3] = o1;
+                for (int q = 0; q < 4; ++q)
+                    if (src[q])
+                        for (int k = 0; k < 32 && slot[k] >= 0; ++k)  // transposed inside each group, see MSQ_QV_BYTE
+                            (*dst[q])[(g0 + gi) * 32 + MSQ_QV_BYTE(slot[k])] = src[q][b0 + (int64_t)gi * 32 + k];
             }
-            for (int k = 0; k < 4; ++k)
-                if (src[k])
-                    for (int64_t i = 0; i < len; ++i)  // transposed inside each group, see MSQ_QV_BYTE
-                        (*dst[k])[(g0 + (uint64_t)(i >> 5)) * 32 + MSQ_QV_BYTE(i & 31)] = src[k][b0 + i];
         }
         msq_packed_reads& v = p->view;
         v.n_reads = n_reads;
@@ -118,7 +128,7 @@ extern "C" int msq_pack_reads(uint64_t n_reads, const int32_t* ref_start, const 
         v.delqv = delqv ? p->delqv.data() : nullptr;
         v.subqv = subqv ? p->subqv.data() : nullptr;
         v.insqv = insqv ? p->insqv.data() : nullptr;
-        v.flags = exotic ? MSQ_READS_HAS_EXOTIC : 0u;
+        v.flags = (exotic ? MSQ_READS_HAS_EXOTIC : 0u) | MSQ_READS_NORMALIZED;
         v.reserved = 0;
     } catch (const std::bad_alloc&) {
         delete p;

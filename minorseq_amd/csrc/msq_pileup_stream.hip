@@ -47,7 +47,7 @@ constexpr int kRows = 8;          // reads per wave batch
 constexpr int kMaxBatchesPerWave = ((1 << kLevels) - 1) / kRows;
 
 // Waves per workgroup (one workgroup per CU): 12 = 3 per SIMD where the kernel fits 168 VGPRs, else 8 = 2 per SIMD.
-constexpr int max_waves_of(int np, int passes) { return (np == 0 && passes == 1) ? 12 : 8; }
+constexpr int max_waves_of(int np, int passes) { return (passes == 1 && np <= 2) ? 12 : 8; }
 // Register slots of the chunk pipeline (NS - 1 chunk loads in flight behind the chunk being decoded).
 constexpr int slots_of(int np, int /*passes*/) { return np == 0 ? 4 : np == 1 ? 3 : 2; }
 
@@ -62,6 +62,7 @@ struct StreamArgs {
     int32_t win_begin0, W;
     int32_t G;           // 32-column words: ceil(W / 32)
     int32_t RD;          // words per LDS row (G + 1)
+    uint32_t normalized; // MSQ_READS_NORMALIZED: consuming bases lead every group, no compaction needed
     uint32_t* nuc;
     uint32_t* codon;
     uint32_t* partials;  // [gridDim.x][NC + 1][G*32]
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         uint32_t b0 = (w.x & (pv | op1)) | masked;  // code bit 0; for X: 1 = 'N' (literal N is op 1 code 1)
         uint32_t b1 = w.y & pv;
         const int n = __popc(cons);
-        if (!(MSQ_EXP & 4)) squeeze4(cons, pv, px, b0, b1);
+        if (!(MSQ_EXP & 4) && !a.normalized) squeeze4(cons, pv, px, b0, b1);  // wave-uniform
         const int incl = wave_inclusive_scan(n);
         const int excl = incl - n;
         // read borders inside this chunk: lanes from the border on belong to the next read / row
@@ -488,15 +489,15 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     uint32_t qn = 0;  // entries on the deviation queue (wave-uniform)
     // four consecutive rows of one word: match / gap / codon / N masks into levels 0-1 of the counters
     // (returns the weight-4 carries); (row, word) pairs with deviations go on the queue
-    auto rows4 = [&](const int p, const int wofs, const uint32_t* rp, const uint32_t tag, uint32_t (&carry)[NC]) {
+    auto rows4 = [&](const int p, const int wofs, const uint32_t* rp, const int rowb, const uint32_t tag, uint32_t (&carry)[NC]) {
         uint32_t even[NC], twos[NC];  // streaming Harley-Seal: rows fold in pairs as they come
         // the guide words of this lane's columns (valid, code bit 0, code bit 1) and of the next word: re-read from
         // LDS per call, cheaper than twelve more live registers
         const uint4 ga = *reinterpret_cast<const uint4*>(gl + wofs), gb = *reinterpret_cast<const uint4*>(gl + wofs + 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint4 lo = *reinterpret_cast<const uint4*>(rp + i * ROWB);
-            const uint4 hi = *reinterpret_cast<const uint4*>(rp + i * ROWB + 4);
+            const uint4 lo = *reinterpret_cast<const uint4*>(rp + i * rowb);
+            const uint4 hi = *reinterpret_cast<const uint4*>(rp + i * rowb + 4);
             // valid base equal to the guide base
             const uint32_t m_lo = lo.x & ga.x & ~((lo.z ^ ga.y) | (lo.w ^ ga.z));
             const uint32_t m_hi = hi.x & gb.x & ~((hi.z ^ gb.y) | (hi.w ^ gb.z));
@@ -548,17 +549,21 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     // every lane runs phase 2 (no predicate, so qn and the queue bookkeeping stay scalar): a lane without a word
     // in a pass reads the all-zero pad word G of its rows and adds nothing
     auto phase2 = [&]() {
+        // the row stride as the compiler must re-read it per batch: otherwise it hoists a dozen row addresses out
+        // of the batch loop and, short of registers, spills them
+        int rowb = ROWB;
+        asm volatile("" : "+s"(rowb));
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int wofs = (act[p] ? cgp[p] : G) * 4;
             if (p == PASSES - 1 && split) {
                 uint32_t c4[NC];
-                rows4(p, wofs, wrow + rbase * ROWB + wofs, (uint32_t)cgp[p] | ((uint32_t)rbase << 8), c4);
+                rows4(p, wofs, wrow + rbase * rowb + wofs, rowb, (uint32_t)cgp[p] | ((uint32_t)rbase << 8), c4);
                 ripple_all(p, std::integral_constant<int, 2>{}, c4);
             } else {
                 uint32_t c4a[NC], c4b[NC], c8[NC];
-                rows4(p, wofs, wrow + wofs, (uint32_t)cgp[p], c4a);
-                rows4(p, wofs, wrow + 4 * ROWB + wofs, (uint32_t)cgp[p] | (4u << 8), c4b);
+                rows4(p, wofs, wrow + wofs, rowb, (uint32_t)cgp[p], c4a);
+                rows4(p, wofs, wrow + 4 * rowb + wofs, rowb, (uint32_t)cgp[p] | (4u << 8), c4b);
 #pragma unroll
                 for (int k = 0; k < NC; ++k) csa(cnt[p][k][2], c4a[k], c4b[k], cnt[p][k][2], c8[k]);
                 ripple_all(p, std::integral_constant<int, 3>{}, c8);
@@ -789,6 +794,7 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
     a.win_begin0 = win_begin0;
     a.W = W;
     a.G = G; a.RD = RD;
+    a.normalized = (R.flags & MSQ_READS_NORMALIZED) ? 1u : 0u;
     a.nuc = d_nuc;
     a.codon = d_codon;
     a.err = ctx->d_err;

@@ -76,10 +76,12 @@ __global__ __launch_bounds__(256) void synth_group_counts_kernel(msq_synth_param
     n_groups[k] = (n + 31) / 32;
 }
 
+// One group in registers, written in the normalized layout (MSQ_READS_NORMALIZED, include/msq_abi.h): consuming
+// bases take the slots from 0 upwards, the others from 31 downwards, op-3 padding in between.
 struct GroupWriter {
     uint32_t n0, n1, o0, o1;
     uint32_t q[4][8];
-    int k;
+    int up, down;
     uint64_t g;
     __device__ void reset()
     {
@@ -88,13 +90,14 @@ struct GroupWriter {
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 8; ++b) q[a][b] = 0;
-        k = 0;
+        up = 0;
+        down = 31;
     }
     __device__ void flush(uint32_t* bop, uint8_t* const* planes)
     {
-        if (k == 0) return;
-        if (k < 32) {  // padding: op 3
-            const uint32_t pad = ~0u << k;
+        if (up == 0 && down == 31) return;
+        if (up <= down) {  // padding: op 3
+            const uint32_t pad = (0xffffffffu >> (31 - down)) & (0xffffffffu << up);
             o0 |= pad;
             o1 |= pad;
         }
@@ -111,6 +114,7 @@ struct GroupWriter {
     }
     __device__ void push(uint32_t op, uint32_t code, const SynQv& v, uint32_t* bop, uint8_t* const* planes)
     {
+        const int k = op < 2u ? up++ : down--;
         n0 |= (code & 1u) << k;
         n1 |= ((code >> 1) & 1u) << k;
         o0 |= (op & 1u) << k;
@@ -125,7 +129,7 @@ struct GroupWriter {
                 q[2][b] |= (uint32_t)v.sub << sh;
                 q[3][b] |= (uint32_t)v.ins << sh;
             }
-        if (++k == 32) flush(bop, planes);
+        if (up > down) flush(bop, planes);
     }
 };
 

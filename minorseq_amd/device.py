@@ -154,7 +154,7 @@ def synth_device(ctx, wl, first=0, n=None):
         "subqv": torch.zeros(max(32 * g, 32), dtype=torch.uint8, device=dev) if wl.rich_qv else None,
         "insqv": torch.zeros(max(32 * g, 32), dtype=torch.uint8, device=dev) if wl.rich_qv else None,
     }
-    dr = DeviceReads(n, g, t)
+    dr = DeviceReads(n, g, t, abi.MSQ_READS_NORMALIZED)  # the generator writes normalized groups
     abi.check(L.msq_synth_dev_fill(ctx.h, wl.params, clones.data_ptr(), first, dr.view))
     ctx.sync()
     return dr

@@ -36,19 +36,22 @@ def test_pack_bit_planes():
     p = device.pack_host(reads)
     assert p["n_reads"] == 2 and list(p["group_off"]) == [0, 2, 3] and p["n_groups"] == 3
     bop = p["bop"].reshape(-1, 4)
-    # read 0, group 0: A C - T then 28 G
-    assert bop[0, 0] & 0xF == 0b1010 and bop[0, 1] & 0xF == 0b1000      # A=0 C=1 (D code 0) T=3
-    assert bop[0, 2] & 0xF == 0b0100 and bop[0, 3] & 0xF == 0b1000      # ops 0 0 1 2
-    assert bop[0, 0] >> 4 == 0 and bop[0, 1] >> 4 == 0x0FFFFFFF           # G = 2
-    # group 1: 2 G, P, S then padding (op 3)
+    # normalized groups (MSQ_READS_NORMALIZED): consuming bases from slot 0 up, the others from slot 31 down
+    # read 0, group 0: A C - (I:T -> slot 31) then 28 G
+    assert bop[0, 0] & 0x7 == 0b010 and bop[0, 1] & 0x7 == 0b000         # A=0 C=1 (D code 0)
+    assert bop[0, 2] & 0x7 == 0b100 and bop[0, 3] & 0x7 == 0b000         # ops 0 0 1
+    assert bop[0, 0] >> 3 == 0x10000000 and bop[0, 1] >> 3 == 0x1FFFFFFF   # 28 G = 2, then the inserted T = 3
+    assert bop[0, 2] >> 3 == 0 and bop[0, 3] >> 3 == 0x10000000            # ... op 2 in slot 31
+    # group 1: 2 G, then padding, S in slot 30 and P in slot 31 (all op 3)
     assert bop[1, 2] == 0xFFFFFFFC and bop[1, 3] == 0xFFFFFFFC
+    assert bop[1, 0] == 0 and bop[1, 1] == 0b11
     # read 1: T then literal N -> op 1 code 1
     assert bop[2, 0] & 3 == 0b11 and bop[2, 1] & 3 == 0b01 and bop[2, 2] & 3 == 0b10 and bop[2, 3] & 3 == 0
-    assert p["flags"] == 0
+    assert p["flags"] == abi.MSQ_READS_NORMALIZED
     q = p["qual"].reshape(-1, 32)
     qv_byte = lambda k: 4 * (k & 7) + (k >> 3)  # MSQ_QV_BYTE
     assert all(q[0, qv_byte(k)] == 60 for k in range(32))
-    assert [int(q[1, qv_byte(k)]) for k in range(32)] == [60] * 4 + [0] * 28
+    assert [int(q[1, qv_byte(k)]) for k in range(32)] == [60] * 2 + [0] * 28 + [60] * 2
     assert p["subqv"] is None
 
 
@@ -58,7 +61,7 @@ def test_pack_errors_and_exotic():
         device.pack_host(bad)
     assert e.value.code == abi.MSQ_ERR_CIGAR and "Unexpected cigar 78" in str(e.value)  # std::to_string('N')
     ex = device.pack_host(cases.make_reads([(0, "===", "ARG")]))
-    assert ex["flags"] & abi.MSQ_READS_HAS_EXOTIC
+    assert ex["flags"] & abi.MSQ_READS_HAS_EXOTIC and ex["flags"] & abi.MSQ_READS_NORMALIZED
     empty = device.pack_host(cases.make_reads([]))
     assert empty["n_reads"] == 0 and empty["n_groups"] == 0
 
