@@ -33,6 +33,57 @@ def make_reads(reads, rich=False, qual=True):
     return out
 
 
+def pack_plain(reads):
+    """The packed read format of include/msq_abi.h in its PLAIN layout (base j of a group in slot j, no
+    MSQ_READS_NORMALIZED flag), written from the header's text alone: what a third-party producer may hand to
+    msq_pileup.  Returns the dict layout of minorseq_amd.device.pack_host()."""
+    n = reads["n_reads"]
+    off = reads["base_off"]
+    group_off = np.zeros(n + 1, dtype=np.uint64)
+    for r in range(n):
+        group_off[r + 1] = group_off[r] + (int(off[r + 1] - off[r]) + 31) // 32
+    g = int(group_off[n])
+    bop = np.zeros((g, 4), dtype=np.uint32)
+    planes = {f: (np.zeros((g, 32), dtype=np.uint8) if reads.get(f) is not None else None)
+              for f in ("qual", "delqv", "subqv", "insqv")}
+    exotic = False
+    for r in range(n):
+        for i in range(int(off[r]), int(off[r + 1])):
+            j = i - int(off[r])
+            grp, k = int(group_off[r]) + j // 32, j % 32
+            c, nt = chr(reads["cigar"][i]), chr(reads["nuc"][i])
+            if c in "=X":
+                if nt in "ACGT":
+                    op, code = 0, "ACGT".index(nt)
+                elif nt == "N":
+                    op, code = 1, 1
+                elif nt == "-":
+                    op, code, exotic = 1, 3, True
+                else:
+                    op, code, exotic = 1, 2, True
+            elif c == "D":
+                op, code = 1, 0
+            elif c == "I":
+                op, code = 2, "ACGT".index(nt) if nt in "CGT" else 0
+            else:
+                assert c in "PS"
+                op, code = 3, 0
+            for plane, bit in enumerate((code & 1, code >> 1, op & 1, op >> 1)):
+                bop[grp, plane] |= np.uint32(bit << k)
+            for f, a in planes.items():
+                if a is not None:
+                    a[grp, 4 * (k & 7) + (k >> 3)] = reads[f][i]  # MSQ_QV_BYTE
+        last, used = int(group_off[r + 1]) - 1, int(off[r + 1] - off[r]) % 32
+        if used and last >= int(group_off[r]):  # padding after the last base: op 3
+            pad = np.uint32((0xFFFFFFFF << used) & 0xFFFFFFFF)
+            bop[last, 2] |= pad
+            bop[last, 3] |= pad
+    out = {"n_reads": n, "n_groups": g, "ref_start": reads["ref_start"].copy(), "ref_end": reads["ref_end"].copy(),
+           "group_off": group_off, "bop": bop.reshape(-1), "flags": 1 if exotic else 0}
+    out.update({f: (a.reshape(-1) if a is not None else None) for f, a in planes.items()})
+    return out
+
+
 def random_reads(seed, n_reads, W, start0=100, rich=False, p_sub=0.02, p_del=0.03, p_ins=0.03, stagger=True,
                  exotic=False):
     """Noisy reads over a random reference with heavy indels, staggered/short reads and runs of insertions."""

@@ -37,6 +37,28 @@ def test_edge_sets(ctx, name, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", sorted(EDGE) + ["random_indels", "random_rich"])
+def test_plain_layout_reads(ctx, name, mode):
+    """Packed reads in the plain group layout (no MSQ_READS_NORMALIZED; written by tests/cases.pack_plain from the
+    header's text): the kernels compact the groups themselves and must give the same counts."""
+    if name == "random_indels":
+        reads, thr = cases.random_reads(11, 300, 700, p_ins=0.05), (-1, -1, -1, -1)
+    elif name == "random_rich":
+        reads, thr = cases.random_reads(12, 200, 2300, rich=True, p_ins=0.05), (30, 20, 42, 25)
+    else:
+        reads, thr = EDGE[name]
+    m = orc.Msa(reads, thr)
+    packed = cases.pack_plain(reads)
+    assert not packed["flags"] & abi.MSQ_READS_NORMALIZED
+    dr = device.upload(packed, ctx.device)
+    b, e = device.window_bounds(ctx, dr)
+    W = e - b if dr.n_reads else 0
+    nuc, codon = device.pileup(ctx, dr, abi.QvThresholds.make(*thr), b, W, mode=mode)
+    assert (nuc.cpu().numpy()[:W * 6].reshape(W, 6) == m.nuc_counts()).all()
+    assert (codon.cpu().numpy()[:W * 64].reshape(W, 64) == m.codon_counts()).all()
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name,n,rich,thr", [
     ("pol_100k", 3000, False, (-1, -1, -1, -1)),
     ("pol_100k", 1500, False, (75, -1, -1, -1)),
