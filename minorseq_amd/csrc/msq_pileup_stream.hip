@@ -60,8 +60,9 @@ struct StreamArgs {
     uint64_t read_lo, read_hi;  // this launch covers reads [read_lo, read_hi)
     uint64_t n_batches;         // ceil((read_hi - read_lo) / 8)
     int32_t win_begin0, W;
-    int32_t G;           // 32-column words: ceil(W / 32)
-    int32_t RD;          // words per LDS row (G + 1)
+    int32_t slab0;       // first window column of this launch's column slab (a multiple of 32)
+    int32_t G;           // 32-column words of the slab (<= 128)
+    int32_t RD;          // words per LDS row: a margin word, the slab's G words, two margin words, a zero pad word
     uint32_t normalized; // MSQ_READS_NORMALIZED: consuming bases lead every group, no compaction needed
     uint32_t* nuc;
     uint32_t* codon;
@@ -208,20 +209,20 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v)
 
 // Columns of word cg that can start a codon: 1 <= c <= W-3 (MSARow::CodonAt's i > 0, CodingCodonAt's bound;
 // MSA.cpp:193,207).
-__device__ __forceinline__ uint32_t codon_cols_of(int cg, int G, int W)
+__device__ __forceinline__ uint32_t codon_cols_of(int cg, int W)  // cg: word of the window
 {
     const int c0 = cg * 32;
     const int lo = max(1 - c0, 0), hi = min(W - 3 - c0, 31);
-    return (cg < G && lo <= hi) ? (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo) : 0u;
+    return lo <= hi ? (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo) : 0u;
 }
 
-// Per-column majority base over every wave's first batch -> the workgroup's guide words gl[RD][4] (valid,
+// Per-column majority base over every wave's first batch -> the workgroup's guide words gl[G + 1][4] (valid,
 // code bit 0, code bit 1, 0).  Runs once per workgroup; kept out of line so its registers do not add to the
 // streaming loop's budget.  Rows are [8][RD][4 planes V X B0 B1], WV dwords per wave.
 __device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl, int NWV, int WV, int RD, int G, int tid, int T)
 {
     const int ROWB = RD * 4;
-    for (int cg = tid; cg < G; cg += T) {
+    for (int cg = tid; cg <= G; cg += T) {  // word G = the first word behind the slab: codons reach into it
         uint32_t cv[8], c0[8], c1[8];  // 8 levels: up to 255 rows (12 waves x 8 = 96)
 #pragma unroll
         for (int l = 0; l < 8; ++l) cv[l] = c0[l] = c1[l] = 0;
@@ -229,7 +230,7 @@ __device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl
             uint32_t xv[kRows], x0[kRows], x1[kRows];
 #pragma unroll
             for (int i = 0; i < kRows; ++i) {
-                const uint4 w = *reinterpret_cast<const uint4*>(lds + wv * WV + i * ROWB + cg * 4);
+                const uint4 w = *reinterpret_cast<const uint4*>(lds + wv * WV + i * ROWB + (cg + 1) * 4);
                 xv[i] = w.x;
                 x0[i] = w.z & w.x;  // the X cells reuse B0 for 'N': only valid bases vote
                 x1[i] = w.w;
@@ -376,12 +377,14 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, NWV = T >> 6;
     const int wave = (int)uni((uint32_t)tid >> 6);   // tell the compiler it is wave-uniform: all stream control is scalar
     const int RD = a.RD, G = a.G, W = a.W;
+    const int slab0 = a.slab0, wbase = slab0 >> 5;            // window word of the slab's word 0
+    const uint32_t slab_span = 32u * (uint32_t)(G + 1) + 31u;
     const int ROWB = RD * 4;                                  // dwords per row: [RD words][V X B0 B1]
     const int QW = ((kRows * G * 2 + 15) / 16) * 4;           // dwords of the deviation queue (u16 entries)
     const int WV = kRows * ROWB + QW;                         // dwords per wave
     uint32_t* const wrow = lds + wave * WV;                   // this wave's rows
     uint16_t* const queue = reinterpret_cast<uint16_t*>(wrow + kRows * ROWB);
-    uint32_t* const gl = lds + NWV * WV;                      // the workgroup's guide words [RD][4]
+    uint32_t* const gl = lds + NWV * WV;                      // the workgroup's guide words [G + 3][4]
     uint32_t my_err = 0, exotic = 0;
 
     // ---- phase-2 identity: in pass p this lane owns word cgp[p].  The last pass, when at most 32 words wide,
@@ -396,14 +399,14 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     for (int p = 0; p < PASSES; ++p) {
         cgp[p] = (p == PASSES - 1 && split) ? 64 * p + (lane & 31) : 64 * p + lane;
         act[p] = cgp[p] < G;
-        ccols[p] = codon_cols_of(cgp[p], G, W);
+        ccols[p] = act[p] ? codon_cols_of(wbase + cgp[p], W) : 0u;
     }
 
     auto zero_rows = [&]() {  // MSARow(size): all ' '
         for (int i = lane * 4; i < kRows * ROWB; i += 256) *reinterpret_cast<uint4*>(&wrow[i]) = make_uint4(0, 0, 0, 0);
     };
     zero_rows();
-    for (int i = tid; i < 4 * (RD + 1); i += T) gl[i] = 0;
+    for (int i = tid; i < 4 * (G + 3); i += T) gl[i] = 0;
 
     // ---- producer: one unconditional chunk load per call (clamped addresses, no predicate around the loads)
     ChunkProducer pr;
@@ -465,16 +468,18 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         if (n) {
             if (c0 < 0 || c0 + n > W) {
                 my_err |= DEVERR_WINDOW;  // assert(pos >= 0) / write past the row, MSA.cpp:149
-            } else {
-                // the lane's words at bit offset sh of word c0 >> 5: low part, and the spill into the next word
-                const int sh = c0 & 31, rs = 31 - sh;
-                uint64_t* p = reinterpret_cast<uint64_t*>(wrow + rowoffv + (c0 >> 5) * 4);
+            } else if ((uint32_t)(c0 - slab0 + 31) < slab_span) {  // touches the slab or its margin words (-32 < cs0 < 32 (G + 1))
+                // the lane's words at bit offset sh of slab word cs0 >> 5 (row word + 1; -1 = the leading margin):
+                // low part, and the spill into the next word
+                const int cs0 = c0 - slab0;
+                const int sh = cs0 & 31, rs = 31 - sh;
+                uint64_t* p = reinterpret_cast<uint64_t*>(wrow + rowoffv + ((cs0 >> 5) + 1) * 4);
                 const uint64_t lo_vx = (uint64_t)(pv << sh) | ((uint64_t)(px << sh) << 32);
                 const uint64_t lo_b = (uint64_t)(b0 << sh) | ((uint64_t)(b1 << sh) << 32);
                 const uint64_t hi_vx = (uint64_t)((pv >> 1) >> rs) | ((uint64_t)((px >> 1) >> rs) << 32);
                 const uint64_t hi_b = (uint64_t)((b0 >> 1) >> rs) | ((uint64_t)((b1 >> 1) >> rs) << 32);
                 if (MSQ_EXP & 1) {  // timing experiment: keep the operands alive, leave out the LDS atomics
-                    if (((lo_vx ^ lo_b ^ hi_vx ^ hi_b) + (uint64_t)(rowoffv + (c0 >> 5) * 4)) == 0x123456789abcdef1ull) my_err |= DEVERR_RANGE;
+                    if (((lo_vx ^ lo_b ^ hi_vx ^ hi_b) + (uint64_t)(rowoffv + (cs0 >> 5) * 4)) == 0x123456789abcdef1ull) my_err |= DEVERR_RANGE;
                 } else {
                     lds_or64(p, lo_vx);
                     lds_or64(p + 1, lo_b);
@@ -547,7 +552,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         }
     };
     // every lane runs phase 2 (no predicate, so qn and the queue bookkeeping stay scalar): a lane without a word
-    // in a pass reads the all-zero pad word G of its rows and adds nothing
+    // in a pass reads the all-zero pad word of its rows (row word G + 3; guide word G + 1) and adds nothing
     auto phase2 = [&]() {
         // the row stride as the compiler must re-read it per batch: otherwise it hoists a dozen row addresses out
         // of the batch loop and, short of registers, spills them
@@ -555,15 +560,16 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         asm volatile("" : "+s"(rowb));
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int wofs = (act[p] ? cgp[p] : G) * 4;
+            const int wofs = (act[p] ? cgp[p] : G + 1) * 4;         // guide word
+            const int rofs = (act[p] ? cgp[p] + 1 : G + 3) * 4;     // row word
             if (p == PASSES - 1 && split) {
                 uint32_t c4[NC];
-                rows4(p, wofs, wrow + rbase * rowb + wofs, rowb, (uint32_t)cgp[p] | ((uint32_t)rbase << 8), c4);
+                rows4(p, wofs, wrow + rbase * rowb + rofs, rowb, (uint32_t)cgp[p] | ((uint32_t)rbase << 8), c4);
                 ripple_all(p, std::integral_constant<int, 2>{}, c4);
             } else {
                 uint32_t c4a[NC], c4b[NC], c8[NC];
-                rows4(p, wofs, wrow + wofs, rowb, (uint32_t)cgp[p], c4a);
-                rows4(p, wofs, wrow + 4 * rowb + wofs, rowb, (uint32_t)cgp[p] | (4u << 8), c4b);
+                rows4(p, wofs, wrow + rofs, rowb, (uint32_t)cgp[p], c4a);
+                rows4(p, wofs, wrow + 4 * rowb + rofs, rowb, (uint32_t)cgp[p] | (4u << 8), c4b);
 #pragma unroll
                 for (int k = 0; k < NC; ++k) csa(cnt[p][k][2], c4a[k], c4b[k], cnt[p][k][2], c8[k]);
                 ripple_all(p, std::integral_constant<int, 3>{}, c8);
@@ -578,16 +584,16 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         for (uint32_t e = lane; e < nq; e += 64) {
             const uint32_t ent = queue[e];
             const int cg = (int)(ent & 0xffu), row = (int)(ent >> 8);
-            const uint32_t* rp = wrow + row * ROWB + cg * 4;
+            const uint32_t* rp = wrow + row * ROWB + (cg + 1) * 4;
             const uint4 lo = *reinterpret_cast<const uint4*>(rp), hi = *reinterpret_cast<const uint4*>(rp + 4);
             const uint4 gl_lo = *reinterpret_cast<const uint4*>(gl + cg * 4), gl_hi = *reinterpret_cast<const uint4*>(gl + cg * 4 + 4);
-            const uint32_t cc = codon_cols_of(cg, G, W);
+            const uint32_t cc = codon_cols_of(wbase + cg, W);
             const uint32_t m_lo = lo.x & gl_lo.x & ~((lo.z ^ gl_lo.y) | (lo.w ^ gl_lo.z));
             const uint32_t m_hi = hi.x & gl_hi.x & ~((hi.z ^ gl_hi.y) | (hi.w ^ gl_hi.z));
             const uint32_t cm = m_lo & funnel(m_lo, m_hi, 1) & funnel(m_lo, m_hi, 2) & cc;
             const uint32_t cv = lo.x & funnel(lo.x, hi.x, 1) & funnel(lo.x, hi.x, 2) & cc;
             const uint32_t nd = lo.x & ~m_lo, cd = cv & ~cm, nn = COUNT_N ? 0u : (lo.y & lo.z);
-            const int cbase = cg * 32;
+            const int cbase = (wbase + cg) * 32;
             uint32_t bits = nd | cd | nn;
             while (bits) {
                 const int j = __ffs(bits) - 1;
@@ -701,13 +707,15 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
 // bin, gaps to '-', Ns to 'N' (bins 4 and 5, NucleotideConversion.h:69-88).  Block = 64 columns x 4 workgroup
 // lanes; blockIdx.y slices the workgroups further.
 __global__ __launch_bounds__(256) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
-                                                            int W, uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon)
+                                                            int col0, int W, uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);  // column of the slab; col0 + c = column of the window
     const int sub = threadIdx.x >> 6;
     const int per = (n_wg + gridDim.y - 1) / gridDim.y;
     const int wg_lo = blockIdx.y * per, wg_hi = min(n_wg, wg_lo + per);
-    if (c >= W) return;
+    if (c >= cols || col0 + c >= W) return;
+    nuc += (size_t)col0 * 6;
+    codon += (size_t)col0 * 64;
     uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0, cod_sum = 0;
     int cod_idx = -1;
     for (int wg = wg_lo + sub; wg < wg_hi; wg += 4) {
@@ -756,10 +764,11 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
     *handled = false;
     if (R.flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
     if (R.n_groups == 0) return MSQ_OK;
-    const int G = (W + 31) / 32;
-    if (G > 128) return MSQ_OK;  // wider windows: simple kernel (column slabs are future work)
-    const int passes = G <= 64 ? 1 : 2;
-    const int RD = G + 1;
+    // column slabs: windows wider than 128 words (4096 columns) are cut into equal slabs of <= 128 words and the
+    // reads are streamed once per slab (a launch places only the bases that fall into its slab and margins)
+    const int Gtot = (W + 31) / 32;
+    const int n_slabs = (Gtot + 127) / 128;
+    const int Gslab = (Gtot + n_slabs - 1) / n_slabs;
 
     // the QV planes that can mask a base (threshold set and plane present; ArrayRead.inl:67-87), compacted
     StreamArgs a;
@@ -779,54 +788,61 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
     }
     const int NC = np_kernel == 0 ? 3 : 4;
 
-    const size_t wave_lds = (size_t)kRows * RD * 16 + (size_t)((kRows * G * 2 + 15) / 16) * 16;  // rows + deviation queue
-    const size_t shared_lds = (size_t)(RD + 1) * 16;                                                    // guide words
-    // waves per workgroup: as many as fit one CU (LDS, 2-3 waves per SIMD), one workgroup per CU
-    const int max_waves = max_waves_of(np_kernel, passes);
-    int nwv = (int)std::min<size_t>(max_waves, (160 * 1024 - shared_lds - 512) / wave_lds);
-    if (nwv < 1) return MSQ_OK;
-    const uint64_t reads_per_launch = (uint64_t)ctx->n_cu * nwv * kMaxBatchesPerWave * kRows;  // counters hold 1023 reads per wave
-
-    pileup_kernel_fn kern = pick_kernel(np_kernel, passes);
     a.ref_start = R.ref_start;
     a.group_off = R.group_off;
     a.bop = reinterpret_cast<const uint4*>(R.bop);
     a.win_begin0 = win_begin0;
     a.W = W;
-    a.G = G; a.RD = RD;
     a.normalized = (R.flags & MSQ_READS_NORMALIZED) ? 1u : 0u;
     a.nuc = d_nuc;
     a.codon = d_codon;
     a.err = ctx->d_err;
 
     msq_timing_mark_begin(ctx);
-    for (uint64_t lo = 0; lo < R.n_reads; lo += reads_per_launch) {
-        const uint64_t hi = std::min<uint64_t>(R.n_reads, lo + reads_per_launch);
-        const uint64_t n_batches = (hi - lo + kRows - 1) / kRows;
-        int w = nwv, n_wg = ctx->n_cu;
-        if ((uint64_t)n_wg * w > n_batches) {  // small inputs: fewer, thinner workgroups
-            w = (int)std::max<uint64_t>(1, std::min<uint64_t>(w, (n_batches + ctx->n_cu - 1) / ctx->n_cu));
-            n_wg = (int)((n_batches + w - 1) / w);
+    for (int slab = 0; slab < n_slabs; ++slab) {
+        const int G = std::min(Gslab, Gtot - slab * Gslab);
+        const int passes = G <= 64 ? 1 : 2;
+        const int RD = G + 4;
+        const size_t wave_lds = (size_t)kRows * RD * 16 + (size_t)((kRows * G * 2 + 15) / 16) * 16;  // rows + deviation queue
+        const size_t shared_lds = (size_t)(G + 3) * 16;                                                  // guide words
+        // waves per workgroup: as many as fit one CU (LDS, 2-3 waves per SIMD), one workgroup per CU
+        const int max_waves = max_waves_of(np_kernel, passes);
+        const int nwv = (int)std::min<size_t>(max_waves, (160 * 1024 - shared_lds - 512) / wave_lds);
+        if (nwv < 1) return msq_fail(MSQ_ERR_ARG, "msq_pileup: no LDS for a %d-word slab", G);
+        const uint64_t reads_per_launch = (uint64_t)ctx->n_cu * nwv * kMaxBatchesPerWave * kRows;  // counters hold 1023 reads per wave
+        pileup_kernel_fn kern = pick_kernel(np_kernel, passes);
+        a.slab0 = slab * Gslab * 32;
+        a.G = G;
+        a.RD = RD;
+        const bool last_slab = slab == n_slabs - 1;
+        for (uint64_t lo = 0; lo < R.n_reads; lo += reads_per_launch) {
+            const uint64_t hi = std::min<uint64_t>(R.n_reads, lo + reads_per_launch);
+            const uint64_t n_batches = (hi - lo + kRows - 1) / kRows;
+            int w = nwv, n_wg = ctx->n_cu;
+            if ((uint64_t)n_wg * w > n_batches) {  // small inputs: fewer, thinner workgroups
+                w = (int)std::max<uint64_t>(1, std::min<uint64_t>(w, (n_batches + ctx->n_cu - 1) / ctx->n_cu));
+                n_wg = (int)((n_batches + w - 1) / w);
+            }
+            const size_t lds = (size_t)w * wave_lds + shared_lds;
+            // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
+            void* s = nullptr;
+            int rc = msq_scratch(ctx, (size_t)ctx->n_cu * (NC + 1) * Gslab * 32 * 4, &s);
+            if (rc != MSQ_OK) return rc;
+            a.partials = (uint32_t*)s;
+            a.read_lo = lo;
+            a.read_hi = hi;
+            a.n_batches = n_batches;
+            if (lds > 48 * 1024)
+                MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
+            if (last_slab && hi == R.n_reads) msq_timing_mark_end(ctx);
+            MSQ_HIP(hipGetLastError());
+            const int col_blocks = (G * 32 + 63) / 64;
+            const int slices = std::max(1, std::min(n_wg / 8, (2 * ctx->n_cu + col_blocks - 1) / col_blocks));
+            hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(256), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
+                               a.slab0, W, d_nuc, d_codon);
+            MSQ_HIP(hipGetLastError());
         }
-        const size_t lds = (size_t)w * wave_lds + shared_lds;
-        // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
-        void* s = nullptr;
-        int rc = msq_scratch(ctx, (size_t)ctx->n_cu * (NC + 1) * G * 32 * 4, &s);
-        if (rc != MSQ_OK) return rc;
-        a.partials = (uint32_t*)s;
-        a.read_lo = lo;
-        a.read_hi = hi;
-        a.n_batches = n_batches;
-        if (lds > 48 * 1024)
-            MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
-        if (hi == R.n_reads) msq_timing_mark_end(ctx);
-        MSQ_HIP(hipGetLastError());
-        const int col_blocks = (W + 63) / 64;
-        const int slices = std::max(1, std::min(n_wg / 8, (2 * ctx->n_cu + col_blocks - 1) / col_blocks));
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(256), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
-                           W, d_nuc, d_codon);
-        MSQ_HIP(hipGetLastError());
     }
     *handled = true;
     return MSQ_OK;
