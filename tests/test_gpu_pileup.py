@@ -143,3 +143,39 @@ def test_bench_size_properties(ctx):
     pn, pc = device.pileup(ctx, device.synth_device(ctx, wl, 0, k), thr, 2252, W)
     assert (pn.cpu().numpy()[:W * 6].reshape(W, 6) == m.nuc_counts()).all()
     assert (pc.cpu().numpy()[:W * 64].reshape(W, 64) == m.codon_counts()).all()
+
+
+@pytest.mark.parametrize("W,rich,thr", [(5000, False, (-1, -1, -1, -1)), (9000, True, (40, -1, 42, -1))])
+def test_wide_window_stream_mode(ctx, W, rich, thr):
+    """Windows wider than 4096 columns go through the stream kernel's column slabs (forced with MSQ_PILEUP_STREAM):
+    heavy indels, staggered and short reads, codons across slab borders."""
+    reads = cases.random_reads(21 + W, 150, W, rich=rich, p_ins=0.04, p_del=0.04)
+    m = orc.Msa(reads, thr)
+    _, nuc, codon = gpu_counts(ctx, reads, thr, abi.MSQ_PILEUP_STREAM)
+    assert (nuc == m.nuc_counts()).all()
+    assert (codon == m.codon_counts()).all()
+
+
+def test_launch_splitting(ctx):
+    """More reads than one launch's bit-sliced counters hold (1023 per wave): msq_pileup splits the reads over
+    several launches.  3.4e6 short reads; checked through shard additivity and the oracle on a prefix."""
+    from minorseq_amd.synth import Workload, hxb2
+    n, W = 3400000, 100
+    wl = Workload("short", n, 2252, W, [], hxb2())
+    thr = abi.QvThresholds.make()
+    dr = device.synth_device(ctx, wl, 0, n)
+    nuc, codon = device.pileup(ctx, dr, thr, 2252, W, mode=abi.MSQ_PILEUP_STREAM)
+    N = nuc.cpu().numpy()[:W * 6].reshape(W, 6).astype(np.int64)
+    assert (N.sum(1) == n).all()
+    del dr
+    acc_n, acc_c = device.alloc_counts(ctx, W)
+    for first, cnt in ((0, 1000000), (1000000, 1300000), (2300000, 1100000)):
+        part = device.synth_device(ctx, wl, first, cnt)
+        device.pileup(ctx, part, thr, 2252, W, acc_n, acc_c)
+        del part
+    assert torch.equal(acc_n, nuc) and torch.equal(acc_c, codon)
+    k = 3000
+    m = orc.Msa(wl.host_reads(0, k))
+    pn, pc = device.pileup(ctx, device.synth_device(ctx, wl, 0, k), thr, 2252, W)
+    assert (pn.cpu().numpy()[:W * 6].reshape(W, 6) == m.nuc_counts()).all()
+    assert (pc.cpu().numpy()[:W * 64].reshape(W, 64) == m.codon_counts()).all()
