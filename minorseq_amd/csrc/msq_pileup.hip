@@ -12,11 +12,23 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
                              int32_t win_begin0, int32_t W, uint32_t* d_nuc, uint32_t* d_codon, bool* handled);
 
 // ------------------------------------------------------------------------------------------ window bounds
-__global__ void window_bounds_kernel(const int32_t* __restrict__ ref_start, const int32_t* __restrict__ ref_end,
-                                     uint64_t n, int32_t* __restrict__ out /* {min start, max end} */)
+// MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:138-142).  out[0] = max over reads of ~key(start),
+// out[1] = max of key(end), with key(x) = x ^ 0x80000000, the order-preserving map of int32 onto uint32: both
+// maxima start from 0, so one memset initialises them; the host decodes and applies endPos_'s initial value 0.
+__global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __restrict__ ref_start, const int32_t* __restrict__ ref_end,
+                                                            uint64_t n, uint32_t* __restrict__ out)
 {
-    int32_t lo = INT_MAX, hi = 0;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    int32_t lo = INT_MAX, hi = INT_MIN;
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, nthr = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n4 = (((uintptr_t)ref_start | (uintptr_t)ref_end) & 15u) ? 0 : n / 4;  // 16-byte loads when aligned
+    const int4* s4 = reinterpret_cast<const int4*>(ref_start);
+    const int4* e4 = reinterpret_cast<const int4*>(ref_end);
+    for (uint64_t i = tid; i < n4; i += nthr) {
+        const int4 s = s4[i], e = e4[i];
+        lo = min(min(lo, s.x), min(s.y, min(s.z, s.w)));
+        hi = max(max(hi, e.x), max(e.y, max(e.z, e.w)));
+    }
+    for (uint64_t i = n4 * 4 + tid; i < n; i += nthr) {
         lo = min(lo, ref_start[i]);
         hi = max(hi, ref_end[i]);
     }
@@ -35,8 +47,8 @@ __global__ void window_bounds_kernel(const int32_t* __restrict__ ref_start, cons
             lo = min(lo, s_lo[k]);
             hi = max(hi, s_hi[k]);
         }
-        atomicMin(&out[0], lo);
-        atomicMax(&out[1], hi);
+        atomicMax(&out[0], ~((uint32_t)lo ^ 0x80000000u));
+        atomicMax(&out[1], (uint32_t)hi ^ 0x80000000u);
     }
 }
 
@@ -44,24 +56,25 @@ extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, 
 {
     if (!ctx || !d_reads || !begin0 || !end0) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds: NULL argument");
     MSQ_HIP(hipSetDevice(ctx->device));
+    *begin0 = INT_MAX;  // MSAByRow defaults (include/pacbio/data/MSA.h:83-84)
+    *end0 = 0;
+    if (d_reads->n_reads == 0) return MSQ_OK;
+    if (!d_reads->ref_start || !d_reads->ref_end) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds: NULL ref arrays");
     void* s = nullptr;
     int rc = msq_scratch(ctx, 64, &s);
     if (rc != MSQ_OK) return rc;
-    int32_t init[2] = {INT_MAX, 0};
-    MSQ_HIP(hipMemcpyAsync(s, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    if (d_reads->n_reads) {
-        if (!d_reads->ref_start || !d_reads->ref_end) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds: NULL ref arrays");
-        uint64_t blocks = (d_reads->n_reads + 255) / 256;
-        if (blocks > 256) blocks = 256;
-        hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_reads->ref_start,
-                           d_reads->ref_end, d_reads->n_reads, (int32_t*)s);
-        MSQ_HIP(hipGetLastError());
-    }
-    int32_t res[2];
+    MSQ_HIP(hipMemsetAsync(s, 0, 8, ctx->stream));
+    uint64_t blocks = (d_reads->n_reads / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 128 ? 128 : blocks;  // few blocks: their same-address atomics serialise
+    hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_reads->ref_start,
+                       d_reads->ref_end, d_reads->n_reads, (uint32_t*)s);
+    MSQ_HIP(hipGetLastError());
+    uint32_t res[2];
     MSQ_HIP(hipMemcpyAsync(res, s, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     MSQ_HIP(hipStreamSynchronize(ctx->stream));
-    *begin0 = res[0];
-    *end0 = res[1];
+    *begin0 = (int32_t)(~res[0] ^ 0x80000000u);
+    const int32_t hi = (int32_t)(res[1] ^ 0x80000000u);
+    *end0 = hi > 0 ? hi : 0;  // UpdateBoundaries only ever raises endPos_ from 0 (src/MSA.cpp:138-142)
     return MSQ_OK;
 }
 

@@ -499,10 +499,21 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         // the guide words of this lane's columns (valid, code bit 0, code bit 1) and of the next word: re-read from
         // LDS per call, cheaper than twelve more live registers
         const uint4 ga = *reinterpret_cast<const uint4*>(gl + wofs), gb = *reinterpret_cast<const uint4*>(gl + wofs + 4);
+        // with registers to spare (no QV planes in the load slots) all four rows are fetched up front: the LDS
+        // latency is paid once per call, not once per row (the queue write between rows pins the later loads)
+        constexpr bool FETCH_AHEAD = NP == 0;
+        uint4 lo4[FETCH_AHEAD ? 4 : 1], hi4[FETCH_AHEAD ? 4 : 1];
+        if (FETCH_AHEAD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lo4[i] = *reinterpret_cast<const uint4*>(rp + i * rowb);
+                hi4[i] = *reinterpret_cast<const uint4*>(rp + i * rowb + 4);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint4 lo = *reinterpret_cast<const uint4*>(rp + i * rowb);
-            const uint4 hi = *reinterpret_cast<const uint4*>(rp + i * rowb + 4);
+            const uint4 lo = FETCH_AHEAD ? lo4[i] : *reinterpret_cast<const uint4*>(rp + i * rowb);
+            const uint4 hi = FETCH_AHEAD ? hi4[i] : *reinterpret_cast<const uint4*>(rp + i * rowb + 4);
             // valid base equal to the guide base
             const uint32_t m_lo = lo.x & ga.x & ~((lo.z ^ ga.y) | (lo.w ^ ga.z));
             const uint32_t m_hi = hi.x & gb.x & ~((hi.z ^ gb.y) | (hi.w ^ gb.z));
