@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--qualqv", type=int, default=-1, help="QUALQV threshold (env var of the reference); -1 = unset")
     ap.add_argument("--mode", default="auto", choices=["auto", "simple", "stream"])
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)  # name:first:n -> prints the oracle's seconds
+    ap.add_argument("--h2d-steps", type=int, default=0, help="also time K steps that first copy the packed reads from "
+                    "pinned host memory (PCIe-inclusive rate, reported beside `value`, never as it)")
     return ap.parse_args()
 
 
@@ -55,22 +58,58 @@ def load_traffic(kernel, workload, reads, qualqv):
     return None
 
 
-def cpu_baseline(wl, sample):
-    """The oracle's juliet path (MSAByRow + MSAByColumn + CountNumberOfTests + CallVariants) on `sample` reads."""
+def _cpu_worker(args):
+    """One CPU-baseline process: the oracle's juliet path on reads [first, first + n); returns its compute seconds."""
+    name, first, n = args
+    from minorseq_amd import synth
     from oracle import orc
-    reads = wl.host_reads(0, sample)
+    wl = synth.workload(name)
+    reads = wl.host_reads(first, n)  # untimed: the reference, too, is timed from AminoAcidCaller's constructor on
     gb, ge = wl.gene_arrays()
     t0 = time.perf_counter()
-    m = orc.Msa(reads)
-    m.call(gb, ge, wl.reference if wl.use_reference else "")
+    m = orc.Msa(reads)  # MSAByRow + MSAByColumn
+    m.call(gb, ge, wl.reference if wl.use_reference else "")  # CountNumberOfTests + CallVariants' cell loop
     dt = time.perf_counter() - t0
     m.close()
-    return {"value": sample / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads of the same synthetic workload, %.1f s on one host core (oracle/liborc.so)" % (sample, dt)}
+    return dt
+
+
+def cpu_baseline(name, sample):
+    """The oracle (CPU restatement of the reference path; the reference itself is single-threaded) on a bounded
+    sample: one core on `sample` reads, then every host core this job may use as independent processes on
+    sample / 4 reads each (processes, not threads: src/Fisher.cpp:117,131-134 keep statics).  The workers are
+    fresh interpreters (`bench.py --cpu-worker`), started before this process loads the HIP library or touches
+    the GPU."""
+    import subprocess
+
+    def run(jobs):
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", "%s:%d:%d" % j],
+                               stdout=subprocess.PIPE, text=True) for j in jobs]
+        outs = [p.communicate()[0] for p in ps]
+        if any(p.returncode for p in ps):
+            raise SystemExit("cpu baseline worker failed")
+        return [float(o.strip().splitlines()[-1]) for o in outs]
+
+    dt1 = run([(name, 0, sample)])[0]
+    procs = max(1, min(16, os.cpu_count() or 1))  # 16 = the CPU share of a one-GPU box
+    per = max(1000, sample // 4)
+    dts = run([(name, k * per, per) for k in range(procs)])
+    return {"value": sample / dt1, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the same synthetic workload, %.1f s on one host core (oracle/liborc.so)" % (sample, dt1),
+            "all_cores": {"value": procs * per / max(dts), "unit": "reads/s", "cores": procs,
+                          "sample": "%d processes x %d reads, slowest %.1f s" % (procs, per, max(dts))}}
 
 
 def main():
     a = parse()
+    if a.cpu_worker:
+        name, first, n = a.cpu_worker.split(":")
+        print(_cpu_worker((name, int(first), int(n))))
+        return
+    cpu = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.cpu_sample > 0:
+        from minorseq_amd import synth as _synth
+        cpu = cpu_baseline(a.workload, min(a.cpu_sample, a.reads or _synth.workload(a.workload).n_reads))
     import torch
     import torch.distributed as dist
     from minorseq_amd import abi, device, sharding, synth
@@ -138,6 +177,21 @@ def main():
     abi.check(L.msq_timing_enable(ctx.h, 0))
     kernel_ms = sum(ms[:n_ms.value]) / max(1, n_ms.value)
 
+    pcie = None
+    if a.h2d_steps > 0 and world == 1:  # the boundary handing over host buffers: packed reads cross PCIe every step
+        host = {f: t.cpu().pin_memory() for f, t in dr.t.items() if t is not None}
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.h2d_steps):
+            for f, h in host.items():
+                dr.t[f].copy_(h, non_blocking=True)
+            step()
+        barrier()
+        dt1 = (time.perf_counter() - t1) / a.h2d_steps
+        pcie = {"value": reads / dt1, "unit": "reads/s", "ms_per_step": dt1 * 1e3,
+                "host_bytes_per_step": int(sum(h.numel() * h.element_size() for h in host.values()))}
+        del host
+
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -167,8 +221,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kernel_name, wl.name, reads, a.qualqv),
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
         }
-        if world == 1 and a.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(wl, min(a.cpu_sample, reads))
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

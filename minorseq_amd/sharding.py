@@ -23,7 +23,8 @@ def allreduce_bounds(begin0, end0, device):
         return int(begin0), int(end0)
     t = torch.tensor([-int(begin0), int(end0)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return -int(t[0]), int(t[1])
+    lo, hi = t.tolist()  # one device-to-host copy
+    return -int(lo), int(hi)
 
 
 def allreduce_counts(counts):
