@@ -141,6 +141,16 @@ int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thres
  * Synchronises. */
 int msq_pileup_check(msq_ctx* ctx);
 
+/* The per-read gather of AminoAcidCaller::PhaseVariants (src/AminoAcidCaller.cpp:149-160): for every read r of
+ * d_reads and every k < n_pos, MSARow::CodonAt(pos[k]) (src/MSA.cpp:188-195) of the read's row in the window
+ * [win_begin0, win_begin0 + W) under the QV thresholds, as d_keys[r * n_pos + k] = s0 | s1 << 3 | s2 << 6 with
+ * s_j the row symbol at index pos[k] + j: 0 ' ' (read does not cover the column), 1..4 A C G T, 5 '-', 6 'N',
+ * and 7 for an index CodonAt leaves out (i <= 0 or i >= W: the string is shorter there).  Two reads have the same
+ * codon strings at every position exactly when their key rows are equal.  pos is a host array; d_keys is device
+ * memory, [n_reads * n_pos].  Synchronises. */
+int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
+                     int32_t W, int32_t n_pos, const int32_t* pos, uint16_t* d_keys);
+
 /* Measurement aid (no counterpart in the reference): while enabled, every msq_pileup records a HIP event pair
  * on the context's stream around its dominant kernel launch (the one that streams the packed reads), up to
  * max_records pairs; msq_timing_read synchronises, returns the elapsed ms of each pair and resets.

@@ -96,6 +96,7 @@ _SIGNATURES = {
     "msq_window_bounds": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "msq_pileup": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P, C.c_int]),
     "msq_pileup_check": (C.c_int, [_P]),
+    "msq_phase_codons": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "msq_timing_enable": (C.c_int, [_P, C.c_int32]),
     "msq_timing_read": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "msq_plan_create": (C.c_int, [_P, C.c_int32, _P, _P, C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_P)]),

@@ -5,6 +5,7 @@
 // every op of the packed format.  The streaming bit-plane kernel (msq_pileup_stream.hip) is the fast
 // path; msq_pileup() picks between them.
 #include "msq_internal.h"
+#include "msq_rowbuild.h"
 
 #include <climits>
 
@@ -79,21 +80,6 @@ extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, 
 }
 
 // ------------------------------------------------------------------------------------------ simple kernel
-struct QvPlanes {
-    const uint8_t* plane[4];  // qual, del, sub, ins
-    int32_t thr[4];           // -1 = unset
-};
-
-// ArrayBase::MeetQVThresholds (include/pacbio/data/internal/ArrayRead.inl:67-87)
-__device__ __forceinline__ bool meets_qv(const QvPlanes& q, uint64_t base_index)
-{
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (q.thr[k] >= 0 && q.plane[k]) ok = ok && (q.plane[k][base_index] >= (uint8_t)q.thr[k]);
-    return ok;
-}
-
 __global__ __launch_bounds__(256) void pileup_simple_kernel(
     const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ group_off, const uint4* __restrict__ bop,
     QvPlanes qv, uint64_t n_reads, uint64_t read_stride, int32_t win_begin0, int32_t W, int32_t row_bytes, int32_t waves_per_wg,
@@ -112,52 +98,7 @@ __global__ __launch_bounds__(256) void pileup_simple_kernel(
         const uint64_t r = slot * read_stride;  // stride > 1: a strided sample of the reads
         for (int c = lane * 4; c < row_bytes; c += 256) *reinterpret_cast<uint32_t*>(row + c) = 0;  // MSARow(size): ' '
         __syncthreads();
-        if (active) {
-            const uint64_t g0 = group_off[r], g1 = group_off[r + 1];
-            int col = ref_start[r] - win_begin0;  // MSA.cpp:148
-            for (uint64_t gb = g0; gb < g1; gb += 64) {
-                const uint64_t g = gb + lane;
-                uint4 w = make_uint4(0u, 0u, ~0u, ~0u);  // beyond the read: op 3
-                if (g < g1) w = bop[g];
-                const uint32_t cons = ~w.w;  // ops 0 and 1 consume a column
-                const int n = __popc(cons);
-                int incl = n;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int t = __shfl_up(incl, d);
-                    if (lane >= d) incl += t;
-                }
-                int c = col + incl - n;
-                const int total = __shfl(incl, 63);
-                for (int k = 0; k < 32; ++k) {
-                    const uint32_t op = ((w.z >> k) & 1u) | (((w.w >> k) & 1u) << 1);
-                    if (op >= 2) continue;  // 'I' (MSA.cpp:172-174), 'P'/'S'/padding (:175-180)
-                    const uint32_t code = ((w.x >> k) & 1u) | (((w.y >> k) & 1u) << 1);
-                    int sym;
-                    if (op == 0) {
-                        sym = meets_qv(qv, g * 32 + MSQ_QV_BYTE(k)) ? (int)(SYM_A + code) : (int)SYM_N;  // MSA.cpp:163-166
-                    } else if (code == 0) {
-                        sym = SYM_GAP;  // 'D', MSA.cpp:168-171
-                    } else if (code == 1) {
-                        sym = SYM_N;  // literal 'N' nucleotide: 'N' whether or not the QV passes
-                    } else {
-                        const bool ok = meets_qv(qv, g * 32 + MSQ_QV_BYTE(k));
-                        if (code == 2) {
-                            if (ok) my_err |= DEVERR_BASE;  // "Unexpected base", MSA.cpp:85
-                            sym = SYM_N;
-                        } else {
-                            sym = ok ? (int)SYM_GAP : (int)SYM_N;  // literal '-' nucleotide at a match
-                        }
-                    }
-                    if (c < 0 || c >= W)
-                        my_err |= DEVERR_WINDOW;
-                    else
-                        row[c] = (uint8_t)sym;
-                    ++c;
-                }
-                col += total;
-            }
-        }
+        if (active) my_err |= msq_build_row(row, lane, ref_start, group_off, bop, qv, r, win_begin0, W);
         __syncthreads();
         if (active) {
             for (int c = lane; c < W; c += 64) {

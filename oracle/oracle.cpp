@@ -26,6 +26,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -500,6 +501,141 @@ int64_t orc_call(void* h, int n_genes, const int32_t* gene_begin, const int32_t*
         }
     }
     return C;
+}
+
+// ---------------------------------------------------------------- phasing (src/AminoAcidCaller.cpp:126-323)
+namespace {
+// include/pacbio/juliet/Haplotype.h:46-54
+enum { HT_REPORT = 0, HT_WITH_GAP = 1, HT_WITH_HETERODUPLEX = 2, HT_PARTIAL = 4, HT_LOW_COV = 8, HT_OFFTARGET = 16 };
+// Haplotype (Haplotype.h:56-126, Haplotype.inl, src/Haplotype.cpp:50-57); a read's name is its index here
+struct Hap
+{
+    std::string name;
+    std::vector<int64_t> reads;
+    std::vector<std::string> codons;
+    double frequency = 0;
+    int flags = 0;
+    Hap(int64_t read, std::vector<std::string>&& c, int flag) : reads({read}), codons(std::move(c))
+    {
+        flags |= flag;
+        for (const auto& x : codons) {  // SetFlagsByCodons
+            if (x.find('-') != std::string::npos) flags |= HT_WITH_GAP;
+            if (x.find('N') != std::string::npos) flags |= HT_WITH_HETERODUPLEX;
+            if (x.find(' ') != std::string::npos) flags |= HT_PARTIAL;
+        }
+    }
+    double Size() const { return (double)reads.size(); }  // softCollapses_ stays 0 on this path
+};
+std::string show_codon(const std::string& c)
+{
+    if (c.empty()) return ".";
+    std::string o = c;
+    for (auto& ch : o)
+        if (ch == ' ') ch = '_';
+    return o;
+}
+void emit_hap(std::string& out, const char* tag, const Hap& h)
+{
+    char buf[128];
+    std::snprintf(buf, sizeof buf, "%s %s %zu %d %.17g", tag, h.name.empty() ? "." : h.name.c_str(), h.reads.size(), h.flags,
+                  h.frequency);
+    out += buf;
+    out += ' ';
+    for (size_t i = 0; i < h.codons.size(); ++i) out += (i ? "," : "") + show_codon(h.codons[i]);
+    out += "\nREADS";
+    for (int64_t r : h.reads) out += " " + std::to_string(r);
+    out += "\n";
+}
+}  // namespace
+
+// PhaseVariants on this MSA's rows.  pos[k] = the argument the reference hands to MSARow::CodonAt for variant
+// position k (pos_var.first - BeginPos() - 3, :154); hits = per position the codons VariantPosition::IsHit accepts
+// (src/VariantGene.cpp:84-97: refCodon, altRefCodon, every stored variant codon), '|'-separated inside a position,
+// ';' between positions.  Writes a text report (GEN / FIL / READS / CNT lines, see tests) into out; returns its
+// length (call again with a larger cap when it exceeds cap).
+int64_t orc_phase(void* h, int n_pos, const int32_t* pos, const char* hits, char* out, int64_t cap)
+{
+    Msa* m = static_cast<Msa*>(h);
+    std::vector<std::vector<std::string>> hit(n_pos);
+    {
+        int k = 0;
+        std::string cur;
+        for (const char* p = hits;; ++p) {
+            if (*p == '|' || *p == ';' || *p == 0) {
+                if (k < n_pos) hit[k].push_back(cur);
+                cur.clear();
+                if (*p == ';') ++k;
+                if (*p == 0) break;
+            } else {
+                cur += *p;
+            }
+        }
+    }
+    std::vector<std::shared_ptr<Hap>> observations;
+    for (size_t r = 0; r < m->rows.size(); ++r) {  // :149-196
+        std::vector<std::string> codons;
+        int flag = HT_REPORT;
+        for (int k = 0; k < n_pos; ++k) {
+            const std::string codon = codon_at(m->rows[r], pos[k]);
+            if (std::find(hit[k].begin(), hit[k].end(), codon) == hit[k].end()) flag = HT_OFFTARGET;
+            codons.emplace_back(codon);
+        }
+        bool miss = true;
+        for (auto& hp : observations) {
+            if (hp->codons.size() != codons.size()) continue;
+            if (hp->codons == codons) {
+                hp->reads.push_back((int64_t)r);
+                miss = false;
+                break;
+            }
+        }
+        if (miss) observations.emplace_back(std::make_shared<Hap>((int64_t)r, std::move(codons), flag));
+    }
+    std::vector<std::shared_ptr<Hap>> generators, filtered;  // :198-209
+    for (auto& hp : observations) {
+        if (hp->Size() < 10) hp->flags |= HT_LOW_COV;
+        if (hp->flags == 0)
+            generators.emplace_back(std::move(hp));
+        else
+            filtered.emplace_back(std::move(hp));
+    }
+    auto comp = [](const std::shared_ptr<Hap>& a, const std::shared_ptr<Hap>& b) { return a->Size() < b->Size(); };
+    std::sort(generators.begin(), generators.end(), comp);  // :215-216
+    std::sort(filtered.begin(), filtered.end(), comp);
+    double counts = 0;
+    for (auto& hn : generators) counts += hn->Size();
+    std::stable_sort(generators.begin(), generators.end(),  // :227-230, the reference's >= comparator as it stands
+                     [](const std::shared_ptr<Hap>& a, const std::shared_ptr<Hap>& b) { return a->Size() >= b->Size(); });
+    const bool doubleName = generators.size() > 26;
+    for (size_t g = 0; g < generators.size(); ++g) {  // :234-246
+        auto& hn = generators[g];
+        hn->frequency = hn->Size() / counts;
+        hn->name = doubleName ? std::string(1, (char)('A' + g / 26)) + std::string(1, (char)('a' + g % 26))
+                              : std::string(1, (char)('A' + g));
+    }
+    int genCounts = 0, lowCov = 0, margOff = 0, margGap = 0, margHet = 0, margPartial = 0;  // :286-310
+    std::string text;
+    for (auto& hn : generators) {
+        genCounts += (int)hn->reads.size();
+        emit_hap(text, "GEN", *hn);
+    }
+    std::map<int, int> filteredCounts;
+    for (auto& hp : filtered) {
+        filteredCounts[hp->flags] += (int)hp->reads.size();
+        emit_hap(text, "FIL", *hp);
+    }
+    for (const auto& kv : filteredCounts) {
+        if (kv.first & HT_WITH_GAP) margGap += kv.second;
+        if (kv.first & HT_WITH_HETERODUPLEX) margHet += kv.second;
+        if (kv.first & HT_PARTIAL) margPartial += kv.second;
+        if (kv.first == HT_LOW_COV) lowCov += kv.second;
+        if (kv.first & HT_OFFTARGET) margOff += kv.second;
+    }
+    char buf[160];
+    std::snprintf(buf, sizeof buf, "CNT %d %d %d %d %d %d\n", genCounts, lowCov, margOff, margGap, margHet, margPartial);
+    text += buf;
+    if ((int64_t)text.size() + 1 <= cap) std::memcpy(out, text.c_str(), text.size() + 1);
+    return (int64_t)text.size() + 1;
 }
 
 }  // extern "C"

@@ -56,6 +56,8 @@ def lib():
         l.orc_count_positions.argtypes = [C.c_int, P, P]
         l.orc_call.restype = C.c_int64
         l.orc_call.argtypes = [P, C.c_int, P, P, C.c_char_p, P, C.c_double, P, P, P]
+        l.orc_phase.restype = C.c_int64
+        l.orc_phase.argtypes = [P, C.c_int, P, C.c_char_p, P, C.c_int64]
         _lib = l
     return _lib
 
@@ -90,6 +92,24 @@ def fisher(a, b, c, d):
 
 def _p(a):
     return None if a is None else a.ctypes.data
+
+
+def parse_phase_report(text):
+    """GEN / FIL lines (name size flags frequency codons) each followed by a READS line, then CNT: -> dict."""
+    out = {"gen": [], "fil": [], "cnt": None}
+    cur = None
+    for line in text.splitlines():
+        t = line.split(" ")
+        if t[0] in ("GEN", "FIL"):
+            cur = {"name": t[1], "size": int(t[2]), "flags": int(t[3]), "frequency": float(t[4]),
+                   "codons": [("" if c == "." else c.replace("_", " ")) for c in t[5].split(",")] if len(t) > 5 and t[5] else [],
+                   "reads": []}
+            out["gen" if t[0] == "GEN" else "fil"].append(cur)
+        elif t[0] == "READS":
+            cur["reads"] = [x for x in t[1:] if x]
+        elif t[0] == "CNT":
+            out["cnt"] = [int(x) for x in t[1:7]]
+    return out
 
 
 class Msa:
@@ -152,6 +172,19 @@ class Msa:
             raise RuntimeError("oracle orc_call failed with %d" % n)
         pos_np = np.frombuffer(pos, dtype=np.int32).reshape(-1, 10)[:P].copy()
         return pos_np, [cells[k] for k in range(n)], nt.value
+
+    def phase(self, pos, hits):
+        """PhaseVariants on the rows: pos[k] = CodonAt argument of variant position k, hits[k] = codons IsHit accepts.
+        Returns parse_phase_report() of the oracle's text report."""
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        text = ";".join("|".join(h) for h in hits).encode()
+        cap = 1 << 20
+        while True:
+            buf = C.create_string_buffer(cap)
+            need = lib().orc_phase(self.h, len(pos), _p(pos), text, C.cast(buf, C.c_void_p), cap)
+            if need <= cap:
+                return parse_phase_report(buf.value.decode())
+            cap = int(need)
 
     def close(self):
         if self.h:

@@ -202,3 +202,42 @@ def call_variants(msa, genes, reference, match, substitution, deletion, maximal_
                 rec["cells"].append({"codon": codon, "count": cnt, "expected": expected, "p": p, "frequency": freq,
                                      "variable": freq < 0.8, "significant": p < alpha})
     return tests, out
+
+
+def phase_variants(msa, pos, hits):
+    """AminoAcidCaller::PhaseVariants (src/AminoAcidCaller.cpp:126-323) up to the ordering of equal-sized
+    haplotypes: exact-tuple clustering in read order, Haplotype flags (src/Haplotype.cpp:50-57), LOW_COV below 10
+    reads, generators = flag-free haplotypes.  Returns (generators, filtered, counts) with haplotypes as dicts
+    {codons, reads, flags}; counts = [genCounts, lowCov, margOfftarget, margWithGap, margWithHetero, margPartial]."""
+    obs, index = [], {}
+    for r, row in enumerate(msa.rows):
+        codons = tuple(msa.codon_at(row, p) for p in pos)
+        flag = 0
+        for k, c in enumerate(codons):
+            if c not in hits[k]:
+                flag = 16  # OFFTARGET
+        if codons in index:
+            index[codons]["reads"].append(r)
+            continue
+        h = {"codons": list(codons), "reads": [r], "flags": flag}
+        for c in codons:
+            if "-" in c:
+                h["flags"] |= 1
+            if "N" in c:
+                h["flags"] |= 2
+            if " " in c:
+                h["flags"] |= 4
+        index[codons] = h
+        obs.append(h)
+    gen, fil = [], []
+    for h in obs:
+        if len(h["reads"]) < 10:
+            h["flags"] |= 8
+        (gen if h["flags"] == 0 else fil).append(h)
+    by_flags = {}
+    for h in fil:
+        by_flags[h["flags"]] = by_flags.get(h["flags"], 0) + len(h["reads"])
+    counts = [sum(len(h["reads"]) for h in gen), by_flags.get(8, 0),
+              sum(v for f, v in by_flags.items() if f & 16), sum(v for f, v in by_flags.items() if f & 1),
+              sum(v for f, v in by_flags.items() if f & 2), sum(v for f, v in by_flags.items() if f & 4)]
+    return gen, fil, counts

@@ -179,3 +179,33 @@ def test_launch_splitting(ctx):
     pn, pc = device.pileup(ctx, device.synth_device(ctx, wl, 0, k), thr, 2252, W)
     assert (pn.cpu().numpy()[:W * 6].reshape(W, 6) == m.nuc_counts()).all()
     assert (pc.cpu().numpy()[:W * 64].reshape(W, 64) == m.codon_counts()).all()
+
+
+@pytest.mark.parametrize("seed,W,rich,thr", [(31, 300, False, (-1, -1, -1, -1)), (32, 2500, True, (40, -1, 42, -1)),
+                                             (33, 5000, False, (-1, -1, -1, -1))])
+def test_phase_codon_keys(ctx, seed, W, rich, thr):
+    """msq_phase_codons (SURVEY 8f1): per read and position the three row symbols MSARow::CodonAt would string
+    together, against the oracle's rows; indices CodonAt leaves out come back as 7."""
+    reads = cases.random_reads(seed, 200, W, rich=rich, p_ins=0.03, p_del=0.03)
+    m = orc.Msa(reads, thr)
+    rows = m.rows()
+    n = reads["n_reads"]
+    rng = np.random.RandomState(seed)
+    pos = np.array(sorted(set([-3, -2, -1, 0, 1, W - 3, W - 2, W - 1, W] + list(rng.randint(1, W - 3, size=40)))), dtype=np.int32)
+    dr = device.upload(device.pack_host(reads), ctx.device)
+    b, e = device.window_bounds(ctx, dr)
+    keys = torch.zeros(n * len(pos), dtype=torch.int16, device="cuda")
+    abi.check(abi.lib().msq_phase_codons(ctx.h, dr.view, abi.QvThresholds.make(*thr), b, e - b, len(pos), abi.ptr(pos),
+                                         keys.data_ptr()))
+    got = keys.cpu().numpy().view(np.uint16).reshape(n, len(pos))
+    code = {ord(" "): 0, ord("A"): 1, ord("C"): 2, ord("G"): 3, ord("T"): 4, ord("-"): 5, ord("N"): 6}
+    for k, p in enumerate(pos):
+        want = np.zeros(n, dtype=np.uint16)
+        for j in range(3):
+            i = int(p) + j
+            if 0 < i < W:
+                sym = np.array([code[c] for c in rows[:, i]], dtype=np.uint16)
+            else:
+                sym = np.full(n, 7, dtype=np.uint16)
+            want |= sym << (3 * j)
+        assert (got[:, k] == want).all(), (k, p)
