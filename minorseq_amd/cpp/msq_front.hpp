@@ -13,7 +13,8 @@
 //   PacBio::Juliet::TargetGene/DRM/DMutation/ExpectedMinor/TargetConfig (data members only) TargetConfig.h:49-139
 //   PacBio::Juliet::VariantGene                include/pacbio/juliet/VariantGene.h:49-81 (msa context as plain structs)
 //   PacBio::Juliet::AminoAcidCaller            include/pacbio/juliet/AminoAcidCaller.h:90-154 (CallVariants + store policy)
-// Not mirrored in this round: MSAByRow::Rows()/NameToRow (only PhaseVariants needs the per-read rows),
+// Per-read rows (MSAByRow::Rows()/NameToRow) are not materialised: PhaseVariants, their one consumer, gets the
+// codons it asks for from the device (MSAByRow::PhaseKeys).  Not mirrored:
 // per-column insertion maps, JSON serialisation, TargetConfig JSON parsing.
 //
 // Errors: ABI status codes come back as the reference's exceptions -- std::runtime_error("Unexpected cigar ..") /
@@ -32,6 +33,7 @@
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/msq_abi.h"
@@ -212,12 +214,38 @@ public:
     const std::vector<uint32_t>& CodonCounts() const { return codon_; }     // [W][64]
     const uint32_t* DeviceCodonCounts() const { return dCodon_ ? dCodon_->get() : nullptr; }
     size_t NumReads() const { return numReads_; }
+    /// Names of the reads, in row order (MSARow::Read->Name(), src/MSA.cpp:100-104).
+    const std::vector<std::string>& ReadNames() const { return names_; }
+    /// MSARow::CodonAt(pos[k]) of every row, as msq_phase_codons keys: [row][k], three 3-bit symbols each
+    /// (0 ' ', 1..4 ACGT, 5 '-', 6 'N', 7 = index left out by CodonAt); src/MSA.cpp:188-195.
+    std::vector<uint16_t> PhaseKeys(const std::vector<int32_t>& pos) const
+    {
+        std::vector<uint16_t> keys(numReads_ * pos.size());
+        if (keys.empty()) return keys;
+        Msq::DeviceBuffer<uint16_t> dKeys(keys.size());
+        Msq::Check(msq_phase_codons(Msq::Context(), msq_packed_dev_view(dev_.get()), &thr_, beginPos_ - 1, width_,
+                                    (int32_t)pos.size(), pos.data(), dKeys.get()));
+        Msq::Check(msq_pileup_check(Msq::Context()));
+        return dKeys.ToHost();
+    }
+    /// The string MSARow::CodonAt returns for one key of PhaseKeys.
+    static std::string KeyToCodon(uint16_t key)
+    {
+        static const char sym[] = " ACGT-N";
+        std::string codon;
+        for (int j = 0; j < 3; ++j) {
+            const int s = (key >> (3 * j)) & 7;
+            if (s != 7) codon += sym[s];
+        }
+        return codon;
+    }
 
 private:
     void Build(const std::vector<const ArrayRead*>& reads)
     {
         const QvThresholds qv;  // member qvThresholds_ of the reference: read from the environment per MSA (MSA.h:82)
         numReads_ = reads.size();
+        for (const auto* r : reads) names_.push_back(r->Name());
         // flat ArrayBase columns
         std::vector<int32_t> rs, re;
         std::vector<int64_t> off{0};
@@ -255,7 +283,8 @@ private:
         rc = msq_reads_upload(ctx, msq_packed_host_view(packed), &dev);
         msq_packed_host_free(packed);
         Msq::Check(rc);
-        try {
+        dev_.reset(dev, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // kept for PhaseKeys
+        {
             int32_t b0 = 0, e0 = 0;
             Msq::Check(msq_window_bounds(ctx, msq_packed_dev_view(dev), &b0, &e0));
             width_ = reads.empty() ? 0 : e0 - b0;
@@ -263,16 +292,12 @@ private:
             endPos_ = e0;
             dNuc_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 6));
             dCodon_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 64));
-            const msq_qv_thresholds t{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
-            Msq::Check(msq_pileup(ctx, msq_packed_dev_view(dev), &t, b0, width_, dNuc_->get(), dCodon_->get(), MSQ_PILEUP_AUTO));
+            thr_ = msq_qv_thresholds{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
+            Msq::Check(msq_pileup(ctx, msq_packed_dev_view(dev), &thr_, b0, width_, dNuc_->get(), dCodon_->get(), MSQ_PILEUP_AUTO));
             Msq::Check(msq_pileup_check(ctx));  // "Unexpected base ..." -> std::runtime_error
             nuc_ = dNuc_->ToHost();
             codon_ = dCodon_->ToHost();
-        } catch (...) {
-            msq_packed_dev_free(ctx, dev);
-            throw;
         }
-        msq_packed_dev_free(ctx, dev);
         if (!reads.empty()) {  // ++beginPos_, ++endPos_ (src/MSA.cpp:107-108)
             ++beginPos_;
             ++endPos_;
@@ -288,6 +313,9 @@ private:
     size_t numReads_ = 0;
     std::vector<uint32_t> nuc_, codon_;
     std::shared_ptr<Msq::DeviceBuffer<uint32_t>> dNuc_, dCodon_;
+    std::shared_ptr<msq_packed_dev> dev_;  // the packed reads stay in HBM for the phasing pass
+    msq_qv_thresholds thr_{-1, -1, -1, -1};
+    std::vector<std::string> names_;
 };
 
 /// A single MSA column: counts per nucleotide {A, C, G, T, -, N}.
@@ -477,9 +505,69 @@ struct VariantGene  // include/pacbio/juliet/VariantGene.h:49-81
             std::vector<bool> haplotypeHit;
         };
         std::map<char, std::vector<VariantCodon>> aminoAcidToCodons;
-        bool IsVariant() const { return !aminoAcidToCodons.empty(); }
+        bool IsVariant() const { return !aminoAcidToCodons.empty(); }  // src/VariantGene.cpp:83
+        bool IsHit(const std::string& codon) const                       // src/VariantGene.cpp:84-97
+        {
+            if (codon == refCodon || codon == altRefCodon) return true;
+            for (const auto& kv : aminoAcidToCodons)
+                for (const auto& vc : kv.second)
+                    if (codon == vc.codon) return true;
+            return false;
+        }
     };
     std::map<int, std::shared_ptr<VariantPosition>> relPositionToVariant;
+};
+
+enum class HaplotypeType : int  // include/pacbio/juliet/Haplotype.h:46-54
+{
+    REPORT = 0,
+    WITH_GAP = 1,
+    WITH_HETERODUPLEX = 2,
+    PARTIAL = 4,
+    LOW_COV = 8,
+    OFFTARGET = 16
+};
+
+class Haplotype  // include/pacbio/juliet/Haplotype.h:56-126, internal/Haplotype.inl, src/Haplotype.cpp (ToJson: not mirrored)
+{
+public:
+    Haplotype() = delete;
+    Haplotype(const std::string readName, const std::vector<std::string>& codons, const HaplotypeType& flag)
+        : readNames_({readName}), codons_(codons), numCodons_(codons_.size())
+    {
+        AddFlag(flag);
+        SetFlagsByCodons();
+    }
+    double Size() const { return readNames_.size() + softCollapses_; }
+    std::string ConcatCodons() const { return std::accumulate(codons_.begin(), codons_.end(), std::string("")); }
+    const std::vector<std::string>& ReadNames() const { return readNames_; }
+    const std::string& Codon(const int i) const { return codons_.at(i); }
+    size_t NumCodons() const { return numCodons_; }
+    int Flags() const { return flags_; }
+    std::string Name() const { return name_; }
+    double Frequency() const { return frequency_; }
+    void SetFlagsByCodons()  // src/Haplotype.cpp:50-57
+    {
+        for (const auto& c : codons_) {
+            if (c.find('-') != std::string::npos) AddFlag(HaplotypeType::WITH_GAP);
+            if (c.find('N') != std::string::npos) AddFlag(HaplotypeType::WITH_HETERODUPLEX);
+            if (c.find(' ') != std::string::npos) AddFlag(HaplotypeType::PARTIAL);
+        }
+    }
+    void AddFlag(const HaplotypeType& flag) { flags_ |= static_cast<int>(flag); }
+    void Frequency(const double& freq) { frequency_ = freq; }
+    void AddReadName(const std::string& name) { readNames_.push_back(name); }
+    void AddSoftReadCount(const double s) { softCollapses_ += s; }
+    void Name(const std::string& name) { name_ = name; }
+
+private:
+    std::string name_;
+    std::vector<std::string> readNames_;
+    std::vector<std::string> codons_;
+    size_t numCodons_;
+    double softCollapses_ = 0;
+    double frequency_ = 0;
+    int flags_ = 0;
 };
 
 /// Given a MSA, target config, and noise model, compute variant amino acids.
@@ -503,6 +591,99 @@ public:
     int NumberOfTests() const { return numberOfTests_; }
     const PerformanceMetrics& Performance() const { return *pm_; }
     const Data::MSAByRow& Rows() const { return msaByRow_; }
+
+    /// Phase variants into haplotypes (src/AminoAcidCaller.cpp:126-323).  The per-read gather -- CodonAt at every
+    /// variant position for every row -- runs on the GPU over the packed reads still resident in HBM; collapsing
+    /// rows with identical codon tuples is a hash on the returned keys (the same partition, in the same
+    /// first-occurrence order, as the reference's pairwise comparison); flags, ordering and naming are the
+    /// reference's own statements.
+    void PhaseVariants()
+    {
+        std::vector<std::pair<int, std::shared_ptr<VariantGene::VariantPosition>>> variantPositions;
+        for (const auto& vg : variantGenes_)
+            for (const auto& pos_vp : vg.relPositionToVariant)
+                if (pos_vp.second->IsVariant())
+                    variantPositions.emplace_back(std::make_pair(vg.geneOffset + pos_vp.first * 3, pos_vp.second));
+        const size_t K = variantPositions.size();
+        std::vector<int32_t> pos;
+        for (const auto& pos_var : variantPositions) pos.push_back(pos_var.first - msaByRow_.BeginPos() - 3);  // :154
+        const std::vector<uint16_t> keys = msaByRow_.PhaseKeys(pos);
+        const auto& names = msaByRow_.ReadNames();
+
+        std::vector<std::shared_ptr<Haplotype>> observations;
+        std::unordered_map<std::string, size_t> seen;  // key row -> index into observations
+        for (size_t r = 0; r < names.size(); ++r) {
+            const std::string keyRow(reinterpret_cast<const char*>(keys.data() + r * K), K * sizeof(uint16_t));
+            const auto it = seen.find(keyRow);
+            if (it != seen.end()) {
+                observations[it->second]->AddReadName(names[r]);
+                continue;
+            }
+            std::vector<std::string> codons;
+            HaplotypeType flag = HaplotypeType::REPORT;
+            for (size_t k = 0; k < K; ++k) {
+                codons.emplace_back(Data::MSAByRow::KeyToCodon(keys[r * K + k]));
+                if (!variantPositions[k].second->IsHit(codons.back())) flag = HaplotypeType::OFFTARGET;  // :157
+            }
+            seen.emplace(keyRow, observations.size());
+            observations.emplace_back(std::make_shared<Haplotype>(names[r], codons, flag));
+        }
+
+        std::vector<std::shared_ptr<Haplotype>> generators, filtered;  // :198-209
+        for (auto& h : observations) {
+            if (h->Size() < 10) h->AddFlag(HaplotypeType::LOW_COV);
+            if (h->Flags() == 0)
+                generators.emplace_back(std::move(h));
+            else
+                filtered.emplace_back(std::move(h));
+        }
+        auto HaplotypeComp = [](const std::shared_ptr<Haplotype>& a, const std::shared_ptr<Haplotype>& b) {
+            return a->Size() < b->Size();
+        };
+        std::sort(generators.begin(), generators.end(), HaplotypeComp);  // :215-216
+        std::sort(filtered.begin(), filtered.end(), HaplotypeComp);
+        double counts = 0;
+        for (auto& hn : generators) counts += hn->Size();
+        std::stable_sort(generators.begin(), generators.end(),  // :227-230, the reference's >= comparator as it stands
+                         [](const std::shared_ptr<Haplotype>& a, const std::shared_ptr<Haplotype>& b) {
+                             return a->Size() >= b->Size();
+                         });
+        static constexpr int alphabetSize = 26;
+        const bool doubleName = generators.size() > alphabetSize;
+        for (size_t genNumber = 0; genNumber < generators.size(); ++genNumber) {  // :234-270
+            auto& hn = generators.at(genNumber);
+            hn->Frequency(hn->Size() / counts);
+            if (doubleName)
+                hn->Name(std::string(1, 'A' + genNumber / alphabetSize) + std::string(1, 'a' + genNumber % alphabetSize));
+            else
+                hn->Name(std::string(1, 'A' + genNumber));
+            for (size_t i = 0; i < hn->NumCodons(); ++i)
+                for (auto& kv : variantPositions.at(i).second->aminoAcidToCodons)
+                    for (auto& vc : kv.second) vc.haplotypeHit.push_back(hn->Codon(i) == vc.codon);
+            reconstructedHaplotypes_.push_back(*hn);
+        }
+        for (auto& hn : generators) genCounts_ += hn->ReadNames().size();  // :286-290
+        std::map<int, int> filteredCounts;
+        for (auto& h : filtered) {
+            filteredCounts[h->Flags()] += h->ReadNames().size();
+            filteredHaplotypes_.emplace_back(*h);
+        }
+        for (const auto& kv : filteredCounts) {  // :301-310
+            if (kv.first & static_cast<int>(HaplotypeType::WITH_GAP)) margWithGap_ += kv.second;
+            if (kv.first & static_cast<int>(HaplotypeType::WITH_HETERODUPLEX)) margWithHetero_ += kv.second;
+            if (kv.first & static_cast<int>(HaplotypeType::PARTIAL)) margPartial_ += kv.second;
+            if (kv.first == static_cast<int>(HaplotypeType::LOW_COV)) lowCov_ += kv.second;
+            if (kv.first & static_cast<int>(HaplotypeType::OFFTARGET)) margOfftarget_ += kv.second;
+        }
+    }
+    const std::vector<Haplotype>& ReconstructedHaplotypes() const { return reconstructedHaplotypes_; }
+    const std::vector<Haplotype>& FilteredHaplotypes() const { return filteredHaplotypes_; }
+    /// {healthy_reported, healthy_low_coverage, all_damaged, marginal_with_gaps, marginal_with_heteroduplexes,
+    /// marginal_partial_reads}: the counters behind the "haplotype_read_counts" JSON (src/AminoAcidCaller.cpp:610-617)
+    std::array<int, 6> HaplotypeReadCounts() const
+    {
+        return {{genCounts_, lowCov_, margOfftarget_, margWithGap_, margWithHetero_, margPartial_}};
+    }
 
 private:
     Data::MSAByRow msaByRow_;  // declared (and so constructed) before msaByColumn_, as in AminoAcidCaller.h:130-134
@@ -665,6 +846,8 @@ private:
     const double minimalPerc_, maximalPerc_;
     int numberOfTests_ = 1;
     std::unique_ptr<PerformanceMetrics> pm_;
+    std::vector<Haplotype> reconstructedHaplotypes_, filteredHaplotypes_;  // AminoAcidCaller.h:138-139
+    int genCounts_ = 0, margWithGap_ = 0, margWithHetero_ = 0, margPartial_ = 0, lowCov_ = 0, margOfftarget_ = 0;  // :148-153
 };
 }  // namespace Juliet
 }  // namespace PacBio

@@ -106,6 +106,50 @@ static void Dump(const char* name, Juliet::AminoAcidCaller& aac)
     std::printf("PERF %g %g %g %g\n", pm.TruePositives, pm.FalsePositives, pm.FalseNegative, pm.TrueNegative);
 }
 
+static std::string ShowCodon(const std::string& c)  // as oracle/oracle.cpp's report: "" -> ".", ' ' -> '_'
+{
+    if (c.empty()) return ".";
+    std::string o = c;
+    for (auto& ch : o)
+        if (ch == ' ') ch = '_';
+    return o;
+}
+
+static void DumpHaplotype(const char* tag, const Juliet::Haplotype& h)
+{
+    std::printf("%s %s %zu %d %.17g ", tag, h.Name().empty() ? "." : h.Name().c_str(), h.ReadNames().size(), h.Flags(), h.Frequency());
+    for (size_t i = 0; i < h.NumCodons(); ++i) std::printf("%s%s", i ? "," : "", ShowCodon(h.Codon((int)i)).c_str());
+    std::printf("\nREADS");
+    for (const auto& n : h.ReadNames()) std::printf(" %s", n.substr(n.find('/') + 1).c_str());  // "read/<index>"
+    std::printf("\n");
+}
+
+// AminoAcidCaller::PhaseVariants (src/AminoAcidCaller.cpp:126-323) through the front: the variant positions it
+// phases over, the haplotypes in the oracle's report format, and every VariantCodon's haplotypeHit vector.
+static void DumpPhase(const char* name, Juliet::AminoAcidCaller& aac)
+{
+    aac.PhaseVariants();
+    std::printf("PHASE %s\n", name);
+    for (const auto& vg : aac.VariantGenes())
+        for (const auto& pv : vg.relPositionToVariant)
+            if (pv.second->IsVariant())
+                std::printf("VPOS %s %d %d %s %s\n", Tok(vg.geneName).c_str(), vg.geneOffset, pv.first, ShowCodon(pv.second->refCodon).c_str(),
+                            ShowCodon(pv.second->altRefCodon).c_str());
+    for (const auto& h : aac.ReconstructedHaplotypes()) DumpHaplotype("GEN", h);
+    for (const auto& h : aac.FilteredHaplotypes()) DumpHaplotype("FIL", h);
+    const auto c = aac.HaplotypeReadCounts();
+    std::printf("CNT %d %d %d %d %d %d\n", c[0], c[1], c[2], c[3], c[4], c[5]);
+    for (const auto& vg : aac.VariantGenes())
+        for (const auto& pv : vg.relPositionToVariant)
+            for (const auto& aa : pv.second->aminoAcidToCodons)
+                for (const auto& vc : aa.second) {
+                    std::printf("HIT %s %d %s ", Tok(vg.geneName).c_str(), pv.first, vc.codon.c_str());
+                    for (const bool b : vc.haplotypeHit) std::putchar(b ? '1' : '0');
+                    std::putchar('\n');
+                }
+    std::printf("ENDPHASE\n");
+}
+
 int main()
 {
     // FisherTest.EquivalentWithR
@@ -126,6 +170,7 @@ int main()
         Juliet::JulietSettings s;  // no config: one ORF over the window
         Juliet::AminoAcidCaller aac(reads, error, s);
         Dump("noconfig", aac);
+        DumpPhase("noconfig", aac);
 
         Juliet::JulietSettings c;  // two genes in different frames + reference + DRMs + expected minors
         Juliet::DRM drm1{"drugA", {Juliet::DMutation('*', 11, '*')}};
@@ -135,6 +180,7 @@ int main()
         c.TargetConfigUser.referenceSequence = full;
         Juliet::AminoAcidCaller aac2(reads, error, c);
         Dump("config", aac2);
+        DumpPhase("config", aac2);
         c.DRMOnly = true;
         Juliet::AminoAcidCaller aac3(reads, error, c);
         Dump("drmonly", aac3);
@@ -150,6 +196,7 @@ int main()
         Juliet::JulietSettings s;
         Juliet::AminoAcidCaller aac(reads, error, s);  // SUBQV defaults to 42 (src/QvThresholds.cpp:53)
         Dump("rich_default_subqv42", aac);
+        DumpPhase("rich_default_subqv42", aac);
     }
     // exceptions keep the reference's types and texts
     try {

@@ -28,11 +28,22 @@ def dump():
         env.pop(k, None)
     out = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = {"fisher": {}, "reads": {}, "cases": {}, "err": [], "ref": None}
-    cur_reads = cur_case = None
+    d = {"fisher": {}, "reads": {}, "cases": {}, "err": [], "ref": None, "phase": {}}
+    cur_reads = cur_case = cur_phase = None
     for line in out.stdout.splitlines():
         t = line.split(" ")
-        if t[0] == "FISHER":
+        if t[0] == "PHASE":
+            cur_phase = d["phase"].setdefault(t[1], {"vpos": [], "hit": [], "report": []})
+        elif t[0] == "ENDPHASE":
+            cur_phase = None
+        elif cur_phase is not None:
+            if t[0] == "VPOS":
+                cur_phase["vpos"].append((t[1], int(t[2]), int(t[3]), t[4], t[5]))
+            elif t[0] == "HIT":
+                cur_phase["hit"].append((t[1], int(t[2]), t[3], t[4] if len(t) > 4 else ""))
+            else:
+                cur_phase["report"].append(line)
+        elif t[0] == "FISHER":
             d["fisher"][int(t[1])] = float(t[2])
         elif t[0] == "REF":
             d["ref"] = t[1]
@@ -161,6 +172,57 @@ def test_caller_matches_oracle(dump, case):
             best = int(np.argmax(nuc[col]))
             assert wt == ("_" if best == 5 else "ACGT-"[best])
     assert c["perf"][0] == 0  # no expected minors: nothing can be a true positive
+
+
+@pytest.mark.parametrize("case", ["noconfig", "config", "rich_default_subqv42"])
+def test_phase_variants_match_oracle(dump, case):
+    """AminoAcidCaller::PhaseVariants through the front (GPU gather + host clustering) against the oracle's
+    literal restatement on the same reads: haplotypes, their reads, flags, names, frequencies and order, the
+    read-count summary and every haplotypeHit vector (parity unpinned, see oracle/oracle.cpp)."""
+    c = dump["cases"][case]
+    ph = dump["phase"][case]
+    rich = c["reads"] == "rich"
+    m = orc.Msa(to_reads(dump["reads"][c["reads"]], rich), (-1, -1, 42, -1))
+    genes = GENES[case]
+    names = [g[0] for g in genes] or ["Unnamed_ORF"]
+    begin = {g[0]: g[1] for g in genes} or {"Unnamed_ORF": m.begin1}
+    ref = dump["ref"] if genes else ""
+    o_pos, _, _ = m.call([g[1] for g in genes], [g[2] for g in genes], ref)
+    by_key = {(names[int(p[0])], int(p[2])): p for p in o_pos}
+    show = lambda s: "" if s == "." else s.replace("_", " ")
+    pos, hits = [], []
+    assert len(ph["vpos"]) > 0
+    for gene, offset, aa_pos, ref_codon, alt_codon in ph["vpos"]:
+        assert offset == begin[gene]  # VariantGene(gene.name, gene.begin), src/AminoAcidCaller.cpp:419
+        p = by_key[(gene, aa_pos)]
+        if p[5] >= 0:
+            assert show(ref_codon) == CODONS[p[5]]
+        assert show(alt_codon) == (CODONS[p[6]] if p[6] >= 0 else "")
+        pos.append(offset + aa_pos * 3 - m.begin1 - 3)  # :134 and :154
+        assert pos[-1] == int(p[3])                     # ... which is the codon's window column
+        stored = [v[4] for v in c["var"] if v[0] == gene and v[1] == aa_pos]
+        assert stored
+        hits.append([show(ref_codon), show(alt_codon)] + stored)
+    want = m.phase(pos, hits)
+    got = orc.parse_phase_report("\n".join(ph["report"]))
+    assert got["cnt"] == want["cnt"]
+    assert sum(want["cnt"][:1]) + sum(h["size"] for h in want["fil"]) == len(dump["reads"][c["reads"]])
+    for kind in ("gen", "fil"):
+        assert len(got[kind]) == len(want[kind])
+        for g, w in zip(got[kind], want[kind]):
+            assert g == w, (kind, g["codons"], w["codons"])
+    # the major clone and the planted 8 % clone phase into separate haplotypes (under the SubQV mask of the rich
+    # case too few clean minor reads are left)
+    assert len(want["gen"]) >= (1 if rich else 2)
+    # haplotypeHit: one bit per reported haplotype, set when it carries the codon (src/AminoAcidCaller.cpp:253-263)
+    kpos = {(v[0], v[2]): k for k, v in enumerate(ph["vpos"])}
+    assert len(ph["hit"]) == len(c["var"])
+    for gene, aa_pos, codon, bits in ph["hit"]:
+        if (gene, aa_pos) not in kpos:
+            assert bits == ""
+            continue
+        k = kpos[(gene, aa_pos)]
+        assert bits == "".join("1" if h["codons"][k] == codon else "0" for h in want["gen"])
 
 
 def test_minor_clone_is_called(dump):
