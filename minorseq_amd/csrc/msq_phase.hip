@@ -1,8 +1,12 @@
 // msq_phase.hip -- the per-read gather of AminoAcidCaller::PhaseVariants (src/AminoAcidCaller.cpp:149-160):
-// for every read, MSARow::CodonAt at each variant position.  One wave per read builds the read's row in LDS
-// (msq_rowbuild.h) and reads the requested cells back; the clustering of the keys is the caller's.
+// for every read, MSARow::CodonAt at each variant position.  The fast path is the streaming pileup kernel in its
+// PHASE mode (msq_pileup_stream.hip); reads with exotic ops take the kernel below: one wave per read builds the
+// read's row in LDS (msq_rowbuild.h) and reads the requested cells back.  Clustering the keys is the caller's.
 #include "msq_internal.h"
 #include "msq_rowbuild.h"
+
+int msq_phase_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
+                            int32_t W, int32_t n_pos, const int32_t* pos, uint16_t* d_keys, bool* handled);
 
 namespace {
 
@@ -55,6 +59,16 @@ extern "C" int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, c
     if (!pos || !d_keys) return msq_fail(MSQ_ERR_ARG, "msq_phase_codons: NULL positions / keys");
     if (!d_reads->ref_start || !d_reads->group_off || !d_reads->bop) return msq_fail(MSQ_ERR_ARG, "msq_phase_codons: NULL read arrays");
     MSQ_HIP(hipSetDevice(ctx->device));
+    {  // fast path: phase 1 of the streaming pileup kernel + a gather from its LDS rows
+        bool handled = false;
+        int rc = msq_phase_stream_launch(ctx, *d_reads, *thr, win_begin0, W, n_pos, pos, d_keys, &handled);
+        if (rc != MSQ_OK) return rc;
+        if (handled) {
+            MSQ_HIP(hipStreamSynchronize(ctx->stream));
+            return MSQ_OK;
+        }
+    }
+    // reads with exotic ops: one wave per read, byte rows (the simple kernel's row builder)
     const int32_t row_bytes = ((W + 2 + 15) / 16) * 16;
     int waves = 150 * 1024 / (row_bytes ? row_bytes : 16);
     if (waves < 1) return msq_fail(MSQ_ERR_ARG, "msq_phase_codons: window of %d columns exceeds one LDS row", W);

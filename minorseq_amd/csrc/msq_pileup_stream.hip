@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 
 // MSQ_EXP: compile-time timing experiments only (make EXTRA=-DMSQ_EXP=n); any non-zero value gives WRONG counts.
 // bit 0 skip the LDS ORs of phase 1, bit 1 skip phase 2 + drain, bit 2 skip the squeeze, bit 3 skip the drain,
@@ -68,6 +69,11 @@ struct StreamArgs {
     uint32_t* codon;
     uint32_t* partials;  // [gridDim.x][NC + 1][G*32]
     uint32_t* err;
+    // the phasing gather (pileup_kernel<.., PHASE = true>): window positions whose codon starts in this slab
+    const int32_t* ph_pos;  // [ph_n] CodonAt arguments (window columns)
+    const int32_t* ph_idx;  // [ph_n] their index k in the caller's position list
+    int32_t ph_n, ph_total; // positions of this launch, of the caller's list (the key row length)
+    uint16_t* ph_keys;      // [n_reads][ph_total]
 };
 
 __device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int k)  // bits k.. of the 64-bit hi:lo
@@ -367,7 +373,9 @@ struct BatchConsumer {
     }
 };
 
-template <int NP, int PASSES>
+// PHASE = false: the pileup.  PHASE = true: phase 1 only, then the per-read gather of AminoAcidCaller::PhaseVariants
+// (MSARow::CodonAt at the requested positions, src/AminoAcidCaller.cpp:149-160) instead of the counting.
+template <int NP, int PASSES, bool PHASE>
 __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(StreamArgs a)
 {
     constexpr int NS = slots_of(NP, PASSES);
@@ -406,7 +414,15 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         for (int i = lane * 4; i < kRows * ROWB; i += 256) *reinterpret_cast<uint4*>(&wrow[i]) = make_uint4(0, 0, 0, 0);
     };
     zero_rows();
-    for (int i = tid; i < 4 * (G + 3); i += T) gl[i] = 0;
+    if (PHASE) {  // the guide area holds the position list instead: (window column, key index) pairs
+        for (int i = tid; i < a.ph_n; i += T) {
+            gl[2 * i] = (uint32_t)a.ph_pos[i];
+            gl[2 * i + 1] = (uint32_t)a.ph_idx[i];
+        }
+        __syncthreads();
+    } else {
+        for (int i = tid; i < 4 * (G + 3); i += T) gl[i] = 0;
+    }
 
     // ---- producer: one unconditional chunk load per call (clamped addresses, no predicate around the loads)
     ChunkProducer pr;
@@ -623,6 +639,32 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         qn = 0;
     };
 
+    // ---- phasing: MSARow::CodonAt (src/MSA.cpp:188-195) of the batch's eight rows at every listed position, as keys
+    // s0 | s1 << 3 | s2 << 6 (0 ' ', 1..4 ACGT, 5 '-', 6 'N', 7 = index CodonAt leaves out); see msq_phase_codons
+    auto gather = [&]() {
+        const uint64_t r0 = a.read_lo + (uint64_t)cs.b * kRows;
+        for (int it = lane; it < kRows * a.ph_n; it += 64) {
+            const int row = it / a.ph_n, k = it - row * a.ph_n;
+            const uint64_t r = r0 + (uint64_t)row;
+            if (r >= a.read_hi) continue;
+            const int p = (int)gl[2 * k];
+            uint32_t key = 0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int c = p + j;
+                uint32_t sym = 7u;
+                if (c > 0 && c < W) {
+                    const int cs0 = c - slab0, bit = cs0 & 31;
+                    const uint4 w = *reinterpret_cast<const uint4*>(wrow + row * ROWB + ((cs0 >> 5) + 1) * 4);
+                    const uint32_t v = (w.x >> bit) & 1u, x = (w.y >> bit) & 1u, b0 = (w.z >> bit) & 1u, b1 = (w.w >> bit) & 1u;
+                    sym = v ? 1u + (b0 | (b1 << 1)) : x ? 5u + b0 : 0u;
+                }
+                key |= sym << (3 * j);
+            }
+            a.ph_keys[r * (uint64_t)a.ph_total + gl[2 * k + 1]] = (uint16_t)key;
+        }
+    };
+
     // ---- the workgroup's guide = per-column majority base over every wave's first batch
     auto learn_guide = [&]() {
         __syncthreads();  // every wave's first batch is in its rows
@@ -654,18 +696,24 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     // counters come to life, so nothing but the load slots is live across the call.
     bool have = cs.live;
     if (have) chunks();
-    learn_guide();
+    if (!PHASE) {
+        learn_guide();
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p)
+        for (int p = 0; p < PASSES; ++p)
 #pragma unroll
-        for (int k = 0; k < NC; ++k)
+            for (int k = 0; k < NC; ++k)
 #pragma unroll
-            for (int l = 0; l < kLevels; ++l) cnt[p][k][l] = 0;
+                for (int l = 0; l < kLevels; ++l) cnt[p][k][l] = 0;
+    }
     while (have) {  // a wave batch is complete in the rows
-        if (!(MSQ_EXP & 2)) phase2();
-        wave_sync();
-        if (!(MSQ_EXP & (2 | 8))) drain();
-        else qn = 0;
+        if (PHASE) {
+            gather();
+        } else {
+            if (!(MSQ_EXP & 2)) phase2();
+            wave_sync();
+            if (!(MSQ_EXP & (2 | 8))) drain();
+            else qn = 0;
+        }
         // gfx9 counts loads and returnless atomics on one vmcnt; with both kinds pending the compiler must
         // assume out-of-order completion and drains to vmcnt(0) at every later wait.  Retire the atomics
         // here, once per batch, so the chunk loads of the next batch are waited for by count.
@@ -678,6 +726,11 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         if (have) chunks();
     }
 
+    if (PHASE) {
+        if (exotic) my_err |= DEVERR_EXOTIC;
+        if (my_err) atomicOr(a.err, my_err);
+        return;
+    }
     // ---- flush: per column the guide's nucleotide / codon bins (meta), then the bit-sliced counters transposed
     // and reduced over the waves through LDS, stored as this workgroup's partial
     __syncthreads();
@@ -762,15 +815,29 @@ typedef void (*pileup_kernel_fn)(StreamArgs);
 pileup_kernel_fn pick_kernel(int np, int passes)
 {
     if (passes == 1) {
-        return np == 0 ? pileup_kernel<0, 1> : np == 1 ? pileup_kernel<1, 1> : np == 2 ? pileup_kernel<2, 1> : pileup_kernel<4, 1>;
+        return np == 0   ? pileup_kernel<0, 1, false>
+               : np == 1 ? pileup_kernel<1, 1, false>
+               : np == 2 ? pileup_kernel<2, 1, false>
+                         : pileup_kernel<4, 1, false>;
     }
-    return np == 0 ? pileup_kernel<0, 2> : np == 1 ? pileup_kernel<1, 2> : np == 2 ? pileup_kernel<2, 2> : pileup_kernel<4, 2>;
+    return np == 0 ? pileup_kernel<0, 2, false> : np == 1 ? pileup_kernel<1, 2, false> : np == 2 ? pileup_kernel<2, 2, false> : pileup_kernel<4, 2, false>;
+}
+pileup_kernel_fn pick_phase_kernel(int np)
+{
+    return np == 0 ? pileup_kernel<0, 1, true> : np == 1 ? pileup_kernel<1, 1, true> : np == 2 ? pileup_kernel<2, 1, true> : pileup_kernel<4, 1, true>;
 }
 
 }  // namespace
 
-int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
-                             int32_t W, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
+// One streaming pass over the reads per column slab: the pileup (phase == nullptr) or the phasing gather.
+struct PhaseRequest {
+    int32_t n_pos;
+    const int32_t* pos;  // host
+    uint16_t* d_keys;
+};
+
+static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
+                         uint32_t* d_nuc, uint32_t* d_codon, const PhaseRequest* phase, bool* handled)
 {
     *handled = false;
     if (R.flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
@@ -809,22 +876,54 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
     a.codon = d_codon;
     a.err = ctx->d_err;
 
-    msq_timing_mark_begin(ctx);
+    constexpr int kMaxPhasePositions = 1024;  // per launch: 8 KB of LDS for the (column, index) pairs
+    a.ph_pos = a.ph_idx = nullptr;
+    a.ph_n = a.ph_total = 0;
+    a.ph_keys = nullptr;
+    if (!phase) msq_timing_mark_begin(ctx);
     for (int slab = 0; slab < n_slabs; ++slab) {
         const int G = std::min(Gslab, Gtot - slab * Gslab);
-        const int passes = G <= 64 ? 1 : 2;
+        const int passes = phase ? 1 : G <= 64 ? 1 : 2;
         const int RD = G + 4;
+        a.slab0 = slab * Gslab * 32;
+        a.G = G;
+        a.RD = RD;
+        // phasing: the positions whose codon starts in this slab (those left of the window go with the first slab,
+        // those right of it with the last: all their symbols are "left out" anyway), at most kMaxPhasePositions per launch
+        std::vector<int32_t> ph_pos, ph_idx;
+        if (phase)
+            for (int32_t k = 0; k < phase->n_pos; ++k) {
+                const int64_t p = phase->pos[k];
+                const int sl = (int)std::min<int64_t>(n_slabs - 1, std::max<int64_t>(0, p / ((int64_t)Gslab * 32)));
+                if (sl == slab) {
+                    ph_pos.push_back((int32_t)p);
+                    ph_idx.push_back(k);
+                }
+            }
+        if (phase && ph_pos.empty()) continue;
+      for (size_t ph0 = 0; ph0 < (phase ? ph_pos.size() : 1); ph0 += kMaxPhasePositions) {
+        const int ph_n = phase ? (int)std::min<size_t>(kMaxPhasePositions, ph_pos.size() - ph0) : 0;
         const size_t wave_lds = (size_t)kRows * RD * 16 + (size_t)((kRows * G * 2 + 15) / 16) * 16;  // rows + deviation queue
-        const size_t shared_lds = (size_t)(G + 3) * 16;                                                  // guide words
+        const size_t shared_lds = std::max((size_t)(G + 3) * 16, (size_t)ph_n * 8);                      // guide words / position pairs
         // waves per workgroup: as many as fit one CU (LDS, 2-3 waves per SIMD), one workgroup per CU
         const int max_waves = max_waves_of(np_kernel, passes);
         const int nwv = (int)std::min<size_t>(max_waves, (160 * 1024 - shared_lds - 512) / wave_lds);
         if (nwv < 1) return msq_fail(MSQ_ERR_ARG, "msq_pileup: no LDS for a %d-word slab", G);
-        const uint64_t reads_per_launch = (uint64_t)ctx->n_cu * nwv * kMaxBatchesPerWave * kRows;  // counters hold 1023 reads per wave
-        pileup_kernel_fn kern = pick_kernel(np_kernel, passes);
-        a.slab0 = slab * Gslab * 32;
-        a.G = G;
-        a.RD = RD;
+        // the pileup's counters hold 1023 reads per wave and launch; the gather has no such limit
+        const uint64_t reads_per_launch = phase ? R.n_reads : (uint64_t)ctx->n_cu * nwv * kMaxBatchesPerWave * kRows;
+        pileup_kernel_fn kern = phase ? pick_phase_kernel(np_kernel) : pick_kernel(np_kernel, passes);
+        if (phase) {
+            void* s = nullptr;
+            int rc = msq_scratch(ctx, (size_t)ph_n * 8, &s);
+            if (rc != MSQ_OK) return rc;
+            MSQ_HIP(hipMemcpyAsync(s, ph_pos.data() + ph0, (size_t)ph_n * 4, hipMemcpyHostToDevice, ctx->stream));
+            MSQ_HIP(hipMemcpyAsync((char*)s + (size_t)ph_n * 4, ph_idx.data() + ph0, (size_t)ph_n * 4, hipMemcpyHostToDevice, ctx->stream));
+            a.ph_pos = (const int32_t*)s;
+            a.ph_idx = (const int32_t*)s + ph_n;
+            a.ph_n = ph_n;
+            a.ph_total = phase->n_pos;
+            a.ph_keys = phase->d_keys;
+        }
         const bool last_slab = slab == n_slabs - 1;
         for (uint64_t lo = 0; lo < R.n_reads; lo += reads_per_launch) {
             const uint64_t hi = std::min<uint64_t>(R.n_reads, lo + reads_per_launch);
@@ -835,26 +934,45 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
                 n_wg = (int)((n_batches + w - 1) / w);
             }
             const size_t lds = (size_t)w * wave_lds + shared_lds;
-            // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
-            void* s = nullptr;
-            int rc = msq_scratch(ctx, (size_t)ctx->n_cu * (NC + 1) * Gslab * 32 * 4, &s);
-            if (rc != MSQ_OK) return rc;
-            a.partials = (uint32_t*)s;
+            a.partials = nullptr;
+            if (!phase) {
+                // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
+                void* s = nullptr;
+                int rc = msq_scratch(ctx, (size_t)ctx->n_cu * (NC + 1) * Gslab * 32 * 4, &s);
+                if (rc != MSQ_OK) return rc;
+                a.partials = (uint32_t*)s;
+            }
             a.read_lo = lo;
             a.read_hi = hi;
             a.n_batches = n_batches;
             if (lds > 48 * 1024)
                 MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
-            if (last_slab && hi == R.n_reads) msq_timing_mark_end(ctx);
+            if (!phase && last_slab && hi == R.n_reads) msq_timing_mark_end(ctx);
             MSQ_HIP(hipGetLastError());
+            if (phase) continue;
             const int col_blocks = (G * 32 + 63) / 64;
             const int slices = std::max(1, std::min(n_wg / 8, (2 * ctx->n_cu + col_blocks - 1) / col_blocks));
             hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(256), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
                                a.slab0, W, d_nuc, d_codon);
             MSQ_HIP(hipGetLastError());
         }
+        if (phase) MSQ_HIP(hipStreamSynchronize(ctx->stream));  // the host position vectors and the scratch are reused
+      }
     }
     *handled = true;
     return MSQ_OK;
+}
+
+int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
+                             int32_t W, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
+{
+    return stream_launch(ctx, R, thr, win_begin0, W, d_nuc, d_codon, nullptr, handled);
+}
+
+int msq_phase_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
+                            int32_t W, int32_t n_pos, const int32_t* pos, uint16_t* d_keys, bool* handled)
+{
+    const PhaseRequest req{n_pos, pos, d_keys};
+    return stream_launch(ctx, R, thr, win_begin0, W, nullptr, nullptr, &req, handled);
 }

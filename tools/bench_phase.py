@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Time the phasing gather (msq_phase_codons) on a synthetic workload resident in HBM:
+python tools/bench_phase.py [--workload pol_1m] [--reads N] [--positions K] [--steps S] -> one JSON line."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from minorseq_amd import abi, device, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="pol_1m")
+ap.add_argument("--reads", type=int, default=0)
+ap.add_argument("--positions", type=int, default=20)
+ap.add_argument("--steps", type=int, default=5)
+a = ap.parse_args()
+wl = synth.workload(a.workload)
+n = a.reads or wl.n_reads
+ctx = device.Ctx(0)
+dr = device.synth_device(ctx, wl, 0, n)
+b0, e0 = device.window_bounds(ctx, dr)
+W = e0 - b0
+pos = np.linspace(1, W - 4, a.positions).astype(np.int32)  # K codon starts spread over the window
+keys = torch.zeros(n * len(pos), dtype=torch.int16, device="cuda")
+thr = abi.QvThresholds.make()
+L = abi.lib()
+def step():
+    abi.check(L.msq_phase_codons(ctx.h, dr.view, thr, b0, W, len(pos), abi.ptr(pos), keys.data_ptr()))  # synchronises
+step()
+t0 = time.perf_counter()
+for _ in range(a.steps):
+    step()
+dt = (time.perf_counter() - t0) / a.steps
+alg = wl.algorithmic_bytes(n_reads=n)
+print(json.dumps({"kernel": "pileup_kernel<NP,1,PHASE>", "workload": wl.name, "reads": n, "positions": len(pos), "ms": dt * 1e3,
+                  "reads_per_s": n / dt, "algorithmic_bytes": alg, "achieved_GBs": alg / dt / 1e9, "frac_of_8TBs": alg / dt / 8e12}))
