@@ -621,19 +621,23 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             const uint32_t cv = lo.x & funnel(lo.x, hi.x, 1) & funnel(lo.x, hi.x, 2) & cc;
             const uint32_t nd = lo.x & ~m_lo, cd = cv & ~cm, nn = COUNT_N ? 0u : (lo.y & lo.z);
             const int cbase = (wbase + cg) * 32;
-            uint32_t bits = nd | cd | nn;
+            // two tight loops instead of one that carries all three cases: a deviating base (or, without an N
+            // counter, an N) is one atomic on its nucleotide bin, a deviating codon one on its codon bin
+            uint32_t bits = nd | nn;  // disjoint: nd lies in V, nn in X
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
-                const size_t col = (size_t)(cbase + j);
-                if ((nd >> j) & 1u) atomicAdd(&a.nuc[col * 6 + (((lo.z >> j) & 1u) | (((lo.w >> j) & 1u) << 1))], 1u);
-                if ((nn >> j) & 1u) atomicAdd(&a.nuc[col * 6 + 5], 1u);
-                if ((cd >> j) & 1u) {
-                    const uint32_t t0 = funnel(lo.z, hi.z, j) & 7u, t1 = funnel(lo.w, hi.w, j) & 7u;
-                    const uint32_t idx = ((t1 & 1u) << 5) | ((t0 & 1u) << 4) | ((t1 & 2u) << 2) | ((t0 & 2u) << 1) |
-                                         ((t1 & 4u) >> 1) | ((t0 & 4u) >> 2);
-                    atomicAdd(&a.codon[col * 64 + idx], 1u);
-                }
+                const uint32_t code = ((nn >> j) & 1u) ? 5u : (((lo.z >> j) & 1u) | (((lo.w >> j) & 1u) << 1));
+                atomicAdd(&a.nuc[(uint32_t)(cbase + j) * 6u + code], 1u);
+            }
+            bits = cd;
+            while (bits) {
+                const int j = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const uint32_t t0 = funnel(lo.z, hi.z, j) & 7u, t1 = funnel(lo.w, hi.w, j) & 7u;
+                const uint32_t idx = ((t1 & 1u) << 5) | ((t0 & 1u) << 4) | ((t1 & 2u) << 2) | ((t0 & 2u) << 1) |
+                                     ((t1 & 4u) >> 1) | ((t0 & 4u) >> 2);
+                atomicAdd(&a.codon[(uint32_t)(cbase + j) * 64u + idx], 1u);
             }
         }
         qn = 0;
@@ -714,12 +718,13 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             if (!(MSQ_EXP & (2 | 8))) drain();
             else qn = 0;
         }
-        // gfx9 counts loads and returnless atomics on one vmcnt; with both kinds pending the compiler must
-        // assume out-of-order completion and drains to vmcnt(0) at every later wait.  Retire the atomics
-        // here, once per batch, so the chunk loads of the next batch are waited for by count.
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         wave_sync();
         if (!(MSQ_EXP & 16)) zero_rows();
+        // gfx9 counts loads and returnless atomics / stores on one vmcnt; with both kinds pending the compiler must
+        // assume out-of-order completion and drains to vmcnt(0) at every later wait.  Retire them here, once per
+        // batch (behind the row clearing, which does not depend on them), so the chunk loads of the next batch
+        // are waited for by count.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         wave_sync();
         cs.next(lane);
         have = cs.live;
