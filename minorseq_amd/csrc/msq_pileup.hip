@@ -82,7 +82,7 @@ extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, 
 // ------------------------------------------------------------------------------------------ simple kernel
 __global__ __launch_bounds__(256) void pileup_simple_kernel(
     const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ group_off, const uint4* __restrict__ bop,
-    QvPlanes qv, uint64_t n_reads, uint64_t read_stride, int32_t win_begin0, int32_t W, int32_t row_bytes, int32_t waves_per_wg,
+    QvPlanes qv, uint64_t n_reads, int32_t win_begin0, int32_t W, int32_t row_bytes, int32_t waves_per_wg,
     uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon, uint32_t* __restrict__ err)
 {
     extern __shared__ __align__(16) uint8_t lds[];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void pileup_simple_kernel(
     for (uint64_t it = 0; it < iters; ++it) {
         const uint64_t slot = it * total_waves + (uint64_t)blockIdx.x * waves_per_wg + wave;
         const bool active = slot < n_reads;
-        const uint64_t r = slot * read_stride;  // stride > 1: a strided sample of the reads
+        const uint64_t r = slot;
         for (int c = lane * 4; c < row_bytes; c += 256) *reinterpret_cast<uint32_t*>(row + c) = 0;  // MSARow(size): ' '
         __syncthreads();
         if (active) my_err |= msq_build_row(row, lane, ref_start, group_off, bop, qv, r, win_begin0, W);
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void pileup_simple_kernel(
 }
 
 static int launch_simple(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
-                         int32_t W, uint32_t* d_nuc, uint32_t* d_codon, uint64_t n_reads, uint64_t stride, bool timed)
+                         int32_t W, uint32_t* d_nuc, uint32_t* d_codon, uint64_t n_reads)
 {
     const int32_t row_bytes = ((W + 2 + 15) / 16) * 16;
     int waves = 150 * 1024 / row_bytes;
@@ -135,20 +135,13 @@ static int launch_simple(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     QvPlanes q;
     q.plane[0] = R.qual; q.plane[1] = R.delqv; q.plane[2] = R.subqv; q.plane[3] = R.insqv;
     q.thr[0] = thr.qual; q.thr[1] = thr.del; q.thr[2] = thr.sub; q.thr[3] = thr.ins;
-    if (timed) msq_timing_mark_begin(ctx);
+    msq_timing_mark_begin(ctx);
     hipLaunchKernelGGL(pileup_simple_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, ctx->stream, R.ref_start,
-                       R.group_off, reinterpret_cast<const uint4*>(R.bop), q, n_reads, stride, win_begin0, W, row_bytes,
+                       R.group_off, reinterpret_cast<const uint4*>(R.bop), q, n_reads, win_begin0, W, row_bytes,
                        waves, d_nuc, d_codon, ctx->d_err);
-    if (timed) msq_timing_mark_end(ctx);
+    msq_timing_mark_end(ctx);
     MSQ_HIP(hipGetLastError());
     return MSQ_OK;
-}
-
-// The simple kernel over reads 0, stride, 2*stride, ... (n_sample of them): the stream kernel's guide sample.
-int msq_pileup_simple_sample(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
-                             int32_t W, uint64_t n_sample, uint64_t stride, uint32_t* d_nuc, uint32_t* d_codon)
-{
-    return launch_simple(ctx, R, thr, win_begin0, W, d_nuc, d_codon, n_sample, stride, false);
 }
 
 extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,
@@ -175,7 +168,7 @@ extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const m
         if (mode == MSQ_PILEUP_STREAM)
             return msq_fail(MSQ_ERR_ARG, "msq_pileup: streaming kernel not applicable (W=%d, flags=%u)", W, d_reads->flags);
     }
-    return launch_simple(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon, d_reads->n_reads, 1, true);
+    return launch_simple(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon, d_reads->n_reads);
 }
 
 extern "C" int msq_pileup_check(msq_ctx* ctx)
