@@ -171,6 +171,54 @@ __device__ double d_fisher(const LFact& lf, int a, int b, int c, int d, uint32_t
     return base_p;
 }
 
+// fisher_exact_tiss for ONE table evaluated by a whole wave: all 64 lanes call it with the same (a, b, c, d).
+// The reference's loop, p = base_p + sum_k base_p * prod_{j <= k} factorInc_j (src/Fisher.cpp:50-70), runs up to
+// ceil(expected) ~ 1.7e-4 * coverage dependent steps (175 at 1e6 reads, 1400 at 8e6): the latency of the testing
+// pass, and it grows with the node's read count.  Here lane L owns a block of the steps: block products, an
+// exclusive wave prefix product, block sums in units of base_p, a wave sum.  Same terms, another association:
+// a few thousand ulp at most from the sequential sum, far inside the 1e-9 relative the path allows; the rules
+// before the loop (point probability at the table edge, "saddle point" -> 1) are the reference's, unchanged.
+// base_p = the table's point probability (calc_hypergeom), computed beforehand by the cell's own lane so that the
+// log-factorial lookups of all the cells of a position are in flight together.
+// msq_fisher / msq_fisher_batch keep the sequential d_fisher (bit-exact unit door).
+__device__ double d_hypergeom(const LFact& lf, int a, int b, int c, int d, uint32_t* err)  // src/Fisher.cpp:129-143
+{
+    const double b1 = d_binomialln(lf, a + b, a, err);
+    const double b2 = d_binomialln(lf, c + d, c, err);
+    const double b3 = d_binomialln(lf, a + b + c + d, a + c, err);
+    return exp(b1 + b2 - b3);
+}
+__device__ double d_fisher_wave(double base_p, int a, int b, int c, int d, int lane)
+{
+    const int ga = a + b, gb = a + c, total = a + b + c + d;
+    int min_co = 0;
+    if (ga + gb > total) min_co = ga + gb - total;
+    const int max_co = ga < gb ? ga : gb;
+    if (a == max_co || a == min_co) return base_p;
+    if (!(d_factor_inc(a, b, c, d) < d_factor_dec(a, b, c, d))) return 1.0;  // src/Fisher.cpp:71-74
+    const int n = max_co - a;  // steps k = 0 .. n-1 multiply by factorInc(a+k, b-k, c-k, d+k); n = min(b, c) >= 1
+    const int B = (n + 63) >> 6;
+    const int k0 = min(n, lane * B), k1 = min(n, k0 + B);
+    double prod = 1.0;
+    for (int k = k0; k < k1; ++k) prod *= d_factor_inc(a + k, b - k, c - k, d + k);
+    double incl = prod;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const double t = __shfl_up(incl, dd);
+        if (lane >= dd) incl *= t;
+    }
+    double curr = __shfl_up(incl, 1);  // product of every step before this lane's block
+    if (lane == 0) curr = 1.0;
+    double sum = 0.0;
+    for (int k = k0; k < k1; ++k) {
+        curr *= d_factor_inc(a + k, b - k, c - k, d + k);
+        sum += curr;
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) sum += __shfl_xor(sum, dd);
+    return base_p + base_p * sum;
+}
+
 __global__ __launch_bounds__(256) void fisher_batch_kernel(LFact lf, int64_t n, const int32_t* __restrict__ a,
                                                            const int32_t* __restrict__ b, const int32_t* __restrict__ c,
                                                            const int32_t* __restrict__ d, double* __restrict__ p,
@@ -269,7 +317,9 @@ __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restri
         out_pos[p] = o;
     }
     double pv = -1.0, expected = 0.0;
-    if (!skipped && cnt > 0 && lane != ref && lane != alt) {  // :465-472
+    const bool cell = !skipped && cnt > 0 && lane != ref && lane != alt;  // :465-472
+    int tc = 0, td = 0;
+    if (cell) {
         // Probability(refCodon, codon), :325-339: left-to-right product starting from 1
         double pr = 1;
 #pragma unroll
@@ -278,12 +328,25 @@ __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restri
             pr *= (((ref >> sh) & 3) != ((lane >> sh) & 3)) ? em.substitution : em.match;
         }
         expected = coverage * pr;  // :477-478
-        uint32_t e = 0;
-        // :481-485; std::ceil of an int is the int
-        pv = d_fisher(lf, cnt, coverage - cnt, (int)ceil(expected), (int)ceil(coverage - expected), &e) * number_of_tests;
-        if (pv > 1) pv = 1;  // :488
-        if (e) atomicOr(err, e);
+        tc = (int)ceil(expected);  // :481-485; std::ceil of an int is the int
+        td = (int)ceil(coverage - expected);
     }
+    // every cell's point probability by its own lane (the table lookups of the position overlap), then the cells
+    // one after the other, each summation spread over the wave's 64 lanes
+    uint32_t e = 0;
+    const double base_p = cell ? d_hypergeom(lf, cnt, coverage - cnt, tc, td, &e) : 0.0;
+    unsigned long long todo = __ballot(cell);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const double r = d_fisher_wave(__shfl(base_p, src), __shfl(cnt, src), __shfl(coverage - cnt, src), __shfl(tc, src),
+                                       __shfl(td, src), lane);
+        if (lane == src) {
+            pv = r * number_of_tests;
+            if (pv > 1) pv = 1;  // :488
+        }
+    }
+    if (e) atomicOr(err, e);
     out_p[p * 64 + lane] = pv;
     if (out_expected) out_expected[p * 64 + lane] = expected;
 }
