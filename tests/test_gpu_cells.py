@@ -110,3 +110,52 @@ def test_reference_out_of_range_and_small_table(ctx):
                                   plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr())
     assert rc == abi.MSQ_ERR_RANGE  # std::out_of_range of referenceSequence.substr (src/AminoAcidCaller.cpp:446)
     plan.close()
+
+
+@pytest.mark.parametrize("coverage", [1000000, 8000000])
+def test_high_coverage_cells(ctx, coverage):
+    """The testing pass at the coverage of one GPU's shard and of an 8-GPU node (count matrices written directly:
+    no reads needed).  Here the summation loop of fisher_exact_tiss runs 175 / 1400 steps per cell and is spread
+    over the wave (d_fisher_wave): every cell against the oracle's sequential loop, 1e-9 relative."""
+    import torch
+    rng = np.random.RandomState(coverage % 97)
+    W, b1 = 64, 101
+    codon = np.zeros((W, 64), dtype=np.int64)
+    major = rng.randint(0, 64, size=W)
+    em = np.zeros(4)
+    orc.lib().orc_error_estimates_default(em.ctypes.data)
+    match, sub = em[0], em[1]
+    for c in range(1, W - 2):
+        others = [int(major[c]) ^ (d << sh) for sh in (0, 2, 4) for d in (1, 2, 3)]  # one substitution away: long loops
+        picks = rng.choice(others, size=8, replace=False)
+        exp1 = coverage * match * match * sub  # a codon one substitution away
+        for j, k in enumerate(picks):
+            codon[c, k] = [1, 3, int(exp1 * 0.5), int(exp1), int(exp1 * 1.05) + 1, int(exp1 * 1.3), int(exp1 * 3), 40000][j]
+        codon[c, major[c]] = coverage - codon[c].sum()
+    d_codon = torch.from_numpy(codon.astype(np.int32).reshape(-1)).cuda()
+    plan = device.Plan(ctx, [b1], [b1 + W], "", b1, W)
+    ctx.lfact_reserve(2 * coverage + 2)
+    device.call_cells(ctx, plan, d_codon)
+    pos, p, expected, nt = device.results(plan)
+    assert nt == int((codon[[int(x[3]) for x in pos]] > 0).sum())
+    checked = 0
+    for k, row in enumerate(pos):
+        c, cov, ref = int(row[3]), int(row[4]), int(row[5])
+        if not (1 <= c < W - 2):
+            continue
+        assert cov == coverage and ref == major[c]
+        for cod in np.nonzero(codon[c])[0]:
+            if cod == ref:
+                assert p[k, cod] < 0
+                continue
+            pr = 1.0
+            for sh in (4, 2, 0):
+                pr *= sub if ((ref >> sh) & 3) != ((cod >> sh) & 3) else match
+            e = cov * pr
+            assert expected[k, cod] == e
+            cnt = int(codon[c, cod])
+            want = min(1.0, orc.fisher(cnt, cov - cnt, int(np.ceil(e)), int(np.ceil(cov - e))) * nt)
+            assert close(p[k, cod], want), (c, cod, cnt, p[k, cod], want)
+            checked += 1
+    assert checked >= 150
+    plan.close()
