@@ -1,0 +1,279 @@
+// msq_bam.hpp -- BAM decode front: PacBio::IO::BamUtils::BamToArrayReads without pbbam.
+//
+// The reference reads aligned CCS records through pbbam (src/BamUtils.cpp:56-78) and turns each into a
+// BAMArrayRead (src/ArrayRead.cpp:53-99).  pbbam is a submodule the reference does not vendor
+// (.gitmodules:5-8, no pinned commit), so this is a minimal reader written from the SAM/BAM specification
+// (BGZF: RFC 1952 members with the BC extra field; BAM records, SAMv1 section 4) that produces what those two
+// functions produce:
+//   * primary alignments only (flag 0x100 secondary and 0x800 supplementary are skipped, BamUtils.cpp:69-70),
+//     overlapping [regionStart - 1, regionEnd - 1) (BamUtils.cpp:61-62,71), clipped to that reference interval
+//     (record.Clip(CLIP_TO_REFERENCE, ...), :72);
+//   * per remaining alignment column one ArrayBase: cigar char of "MIDNSHP=X" with the clips excised
+//     (CigarData(exciseAllClips = true)), the aligned genomic sequence ('-' at D / N, '*' at P), the aligned
+//     QUAL (0 at D / N / P; a record without QUAL gets QualQV 0 for every base, ArrayRead.cpp:94-96), and -- when
+//     all three of the PacBio tags sq, dq, iq are present (ArrayRead.cpp:74-79) -- the substitution / deletion /
+//     insertion QVs, which BAM stores in native orientation and are reversed for reverse-strand records.
+// Parity unpinned at this boundary: the reference has no BAM fixture, and pbbam's treatment of an
+// insertion that sits exactly on a clip border is not visible from this tree; such an insertion is kept here (it
+// becomes a leading / trailing insertion, which MSAByRow::AddRead does not count: src/MSA.cpp:172-185).
+// Inflating BGZF blocks is spread over hardware threads (blocks are independent); link with -lz.
+#pragma once
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "msq_front.hpp"
+
+namespace PacBio {
+namespace IO {
+namespace detail {
+inline uint32_t U32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline int32_t I32(const uint8_t* p) { return (int32_t)U32(p); }
+inline uint16_t U16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+struct BgzfBlock
+{
+    size_t in_off, in_len;    // the deflate payload inside the file image
+    size_t out_off, out_len;  // where it inflates to (ISIZE)
+};
+
+inline std::vector<uint8_t> ReadFile(const std::string& path)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::vector<uint8_t> data;
+    uint8_t buf[1 << 16];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + n);
+    std::fclose(f);
+    return data;
+}
+
+// BGZF (SAMv1 4.1): gzip members with FEXTRA holding the subfield 'B','C',2,BSIZE; inflate them in parallel.
+inline std::vector<uint8_t> InflateBgzf(const std::vector<uint8_t>& file, unsigned threads)
+{
+    std::vector<BgzfBlock> blocks;
+    size_t off = 0, out = 0;
+    while (off < file.size()) {
+        if (off + 18 > file.size() || file[off] != 31 || file[off + 1] != 139 || file[off + 2] != 8 || !(file[off + 3] & 4))
+            throw std::runtime_error("not a BGZF block");
+        const size_t xlen = U16(&file[off + 10]);
+        size_t x = off + 12, bsize = 0;
+        while (x + 4 <= off + 12 + xlen) {
+            const size_t slen = U16(&file[x + 2]);
+            if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) bsize = (size_t)U16(&file[x + 4]) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || off + bsize > file.size()) throw std::runtime_error("truncated BGZF block");
+        const size_t payload = off + 12 + xlen;
+        const size_t isize = U32(&file[off + bsize - 4]);
+        blocks.push_back({payload, off + bsize - 8 - payload, out, isize});
+        out += isize;
+        off += bsize;
+    }
+    std::vector<uint8_t> data(out);
+    auto work = [&](size_t first, size_t step) {
+        for (size_t b = first; b < blocks.size(); b += step) {
+            const BgzfBlock& k = blocks[b];
+            if (k.out_len == 0) continue;
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("inflateInit2 failed");
+            zs.next_in = const_cast<Bytef*>(&file[k.in_off]);
+            zs.avail_in = (uInt)k.in_len;
+            zs.next_out = &data[k.out_off];
+            zs.avail_out = (uInt)k.out_len;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) throw std::runtime_error("BGZF block does not inflate to its ISIZE");
+        }
+    };
+    threads = std::max(1u, std::min<unsigned>(threads, (unsigned)blocks.size()));
+    if (threads == 1) {
+        work(0, 1);
+    } else {
+        std::vector<std::thread> pool;
+        std::vector<std::string> errors(threads);
+        for (unsigned t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] {
+                try {
+                    work(t, threads);
+                } catch (const std::exception& e) {
+                    errors[t] = e.what();
+                }
+            });
+        for (auto& th : pool) th.join();
+        for (const auto& e : errors)
+            if (!e.empty()) throw std::runtime_error(e);
+    }
+    return data;
+}
+
+// PacBio per-base QV tags are 'Z' strings of Phred + 33 in native orientation
+inline bool FindZTag(const uint8_t* p, const uint8_t* end, char t0, char t1, const uint8_t** val, size_t* len)
+{
+    while (p + 3 <= end) {
+        const char a = (char)p[0], b = (char)p[1], type = (char)p[2];
+        p += 3;
+        size_t skip = 0;
+        switch (type) {
+            case 'A': case 'c': case 'C': skip = 1; break;
+            case 's': case 'S': skip = 2; break;
+            case 'i': case 'I': case 'f': skip = 4; break;
+            case 'Z': case 'H': {
+                const uint8_t* s = p;
+                while (p < end && *p) ++p;
+                if (a == t0 && b == t1 && type == 'Z') {
+                    *val = s;
+                    *len = (size_t)(p - s);
+                    return true;
+                }
+                skip = 1;  // the terminating NUL
+                break;
+            }
+            case 'B': {
+                if (p + 5 > end) return false;
+                const char sub = (char)p[0];
+                const size_t n = U32(p + 1);
+                const size_t w = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : 4;
+                skip = 5 + n * w;
+                break;
+            }
+            default: return false;
+        }
+        p += skip;
+    }
+    return false;
+}
+}  // namespace detail
+
+/// BAMArrayRead (include/pacbio/data/ArrayRead.h:83-94) without the pbbam record behind it.
+class BAMArrayRead : public Data::ArrayRead
+{
+public:
+    BAMArrayRead(int idx, const std::string& name, size_t referenceStart, size_t referenceEnd, std::vector<Data::ArrayBase> bases,
+                 std::string chemistry = "")
+        : Data::ArrayRead(idx, name, referenceStart, referenceEnd, std::move(bases)), chemistry_(std::move(chemistry))
+    {
+    }
+    std::string SequencingChemistry() const override { return chemistry_; }
+
+private:
+    std::string chemistry_;
+};
+
+struct BamUtils
+{
+    /// src/BamUtils.cpp:56-78.  regionStart / regionEnd as juliet passes them (1-based; its defaults are 0 and
+    /// INT_MAX, include/pacbio/juliet/JulietSettings.h:73-74).
+    static std::vector<std::shared_ptr<Data::ArrayRead>> BamToArrayReads(const std::string& filePath, int regionStart,
+                                                                        int regionEnd,
+                                                                        unsigned threads = std::thread::hardware_concurrency())
+    {
+        using namespace detail;
+        std::vector<std::shared_ptr<Data::ArrayRead>> returnList;
+        regionStart = std::max(regionStart - 1, 0);
+        regionEnd = std::max(regionEnd - 1, 0);
+        const std::vector<uint8_t> data = InflateBgzf(ReadFile(filePath), threads ? threads : 1);
+        if (data.size() < 12 || std::memcmp(data.data(), "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file: " + filePath);
+        size_t off = 4;
+        const size_t l_text = U32(&data[off]);
+        off += 4 + l_text;
+        const size_t n_ref = U32(&data[off]);
+        off += 4;
+        for (size_t r = 0; r < n_ref; ++r) {
+            const size_t l_name = U32(&data[off]);
+            off += 4 + l_name + 4;
+        }
+        static const char kSeq[] = "=ACMGRSVTWYHKDBN";
+        static const char kOps[] = "MIDNSHP=X";
+        int idx = 0;
+        while (off + 4 <= data.size()) {
+            const size_t block_size = U32(&data[off]);
+            const uint8_t* rec = &data[off + 4];
+            off += 4 + block_size;
+            if (off > data.size()) throw std::runtime_error("truncated BAM record");
+            const int32_t pos = I32(rec + 4);
+            const size_t l_read_name = rec[8];
+            const size_t n_cigar = U16(rec + 12);
+            const uint16_t flag = U16(rec + 14);
+            const size_t l_seq = U32(rec + 16);
+            if (flag & 0x800) continue;  // IsSupplementaryAlignment
+            if (flag & 0x100) continue;  // !IsPrimaryAlignment
+            if (flag & 0x4) continue;    // unmapped: no reference interval
+            const uint8_t* name = rec + 32;
+            const uint8_t* cigar = name + l_read_name;
+            const uint8_t* seq = cigar + 4 * n_cigar;
+            const uint8_t* qual = seq + (l_seq + 1) / 2;
+            const uint8_t* tags = qual + l_seq;
+            const uint8_t* end = rec + block_size;
+            // reference span
+            int64_t ref_len = 0;
+            for (size_t k = 0; k < n_cigar; ++k) {
+                const uint32_t c = U32(cigar + 4 * k);
+                const int op = c & 15;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+            }
+            const int64_t ref_start = pos, ref_end = pos + ref_len;
+            if (!(ref_start < regionEnd && ref_end > regionStart)) continue;  // BamUtils.cpp:71
+            const bool hasQual = l_seq > 0 && qual[0] != 0xFF;
+            const uint8_t *sq = nullptr, *dq = nullptr, *iq = nullptr;
+            size_t nsq = 0, ndq = 0, niq = 0;
+            const bool rich = FindZTag(tags, end, 's', 'q', &sq, &nsq) && FindZTag(tags, end, 'd', 'q', &dq, &ndq) &&
+                              FindZTag(tags, end, 'i', 'q', &iq, &niq) && nsq == l_seq && ndq == l_seq && niq == l_seq;
+            const bool reverse = flag & 0x10;
+            auto tagQv = [&](const uint8_t* t, size_t q) -> uint8_t {  // tags are native-oriented; SEQ / QUAL genomic
+                const size_t i = reverse ? l_seq - 1 - q : q;
+                return (uint8_t)(t[i] - 33);
+            };
+            // walk the alignment, clipped to [regionStart, regionEnd)
+            const int64_t clip_lo = std::max<int64_t>(ref_start, regionStart), clip_hi = std::min<int64_t>(ref_end, regionEnd);
+            std::vector<Data::ArrayBase> bases;
+            int64_t rp = ref_start;
+            size_t qp = 0;
+            auto emit = [&](char op, char nt, bool has_query, size_t q) {
+                const uint8_t qv = has_query ? (hasQual ? qual[q] : 0) : 0;
+                if (rich)
+                    bases.emplace_back(op, nt, qv, has_query ? tagQv(sq, q) : 0, has_query ? tagQv(dq, q) : 0,
+                                       has_query ? tagQv(iq, q) : 0);
+                else
+                    bases.emplace_back(op, nt, qv);  // a record without QUAL: QualQV 0 (ArrayRead.cpp:94-96)
+            };
+            for (size_t k = 0; k < n_cigar; ++k) {
+                const uint32_t c = U32(cigar + 4 * k);
+                const int op = c & 15;
+                const size_t len = c >> 4;
+                if (op > 8) throw std::runtime_error("bad CIGAR op in " + filePath);
+                const bool cons_ref = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
+                const bool cons_query = op == 0 || op == 1 || op == 4 || op == 7 || op == 8;
+                for (size_t i = 0; i < len; ++i) {
+                    const bool inside = cons_ref ? (rp >= clip_lo && rp < clip_hi) : (rp >= clip_lo && rp <= clip_hi);
+                    if (inside && op != 4 && op != 5) {  // clips are excised
+                        if (cons_query) {
+                            const char nt = kSeq[(seq[qp >> 1] >> ((qp & 1) ? 0 : 4)) & 15];
+                            emit(kOps[op], nt, true, qp);
+                        } else {
+                            emit(kOps[op], op == 6 ? '*' : '-', false, 0);
+                        }
+                    }
+                    if (cons_ref) ++rp;
+                    if (cons_query) ++qp;
+                }
+            }
+            returnList.emplace_back(std::make_shared<BAMArrayRead>(idx++, std::string(reinterpret_cast<const char*>(name)),
+                                                                   (size_t)clip_lo, (size_t)clip_hi, std::move(bases)));
+        }
+        return returnList;
+    }
+};
+}  // namespace IO
+}  // namespace PacBio

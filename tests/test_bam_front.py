@@ -1,0 +1,266 @@
+"""The BAM decode front (minorseq_amd/cpp/msq_bam.hpp = BamUtils::BamToArrayReads, src/BamUtils.cpp:56-78, and
+BAMArrayRead, src/ArrayRead.cpp:53-99, without pbbam).  The test writes its own BAM files (BGZF blocks + records,
+from the SAM/BAM specification), lets tests/cpp/bam_test parse them, and compares every ArrayRead with expectations
+computed here from the same records by a separate walker.  Parity is unpinned at this boundary: the reference holds
+no BAM fixture and pbbam is not vendored; what is checked is the behaviour BamUtils.cpp / ArrayRead.cpp
+spell out (primary filter, region overlap test, clip to the region, excised clips, QV tags reversed for reverse-strand
+records, QualQV 0 without QUAL).  The GPU test feeds a parsed file through AminoAcidCaller and compares the counts
+with the oracle."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import orc, pymodel
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BIN = os.path.join(HERE, "cpp", "bam_test")
+OPS = "MIDNSHP=X"
+SEQ16 = "=ACMGRSVTWYHKDBN"
+INT_MAX = 2147483647
+
+
+# ------------------------------------------------------------------------------------------------ BAM writer
+def bgzf_block(payload):
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = co.compress(payload) + co.flush()
+    bsize = 18 + len(comp) + 8
+    assert bsize <= 65536
+    return (struct.pack("<BBBBIBBH", 31, 139, 8, 4, 0, 0, 255, 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) + comp
+            + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+
+
+def encode_record(rec):
+    name = rec["name"].encode() + b"\0"
+    seq = rec["seq"]
+    packed = bytearray((len(seq) + 1) // 2)
+    for i, c in enumerate(seq):
+        packed[i >> 1] |= SEQ16.index(c) << (0 if i & 1 else 4)
+    qual = bytes(rec["qual"]) if rec["qual"] is not None else b"\xff" * len(seq)
+    cigar = b"".join(struct.pack("<I", (n << 4) | OPS.index(op)) for op, n in rec["cigar"])
+    tags = b""
+    for key, (typ, val) in rec.get("tags", {}).items():
+        tags += key.encode() + typ.encode()
+        if typ == "Z":
+            tags += val.encode() + b"\0"
+        elif typ == "i":
+            tags += struct.pack("<i", val)
+        elif typ == "f":
+            tags += struct.pack("<f", val)
+        elif typ == "C":
+            tags += struct.pack("<B", val)
+        elif typ == "B":  # ('S', [..])
+            sub, arr = val
+            tags += sub.encode() + struct.pack("<I", len(arr)) + b"".join(struct.pack("<H", x) for x in arr)
+    body = struct.pack("<iiBBHHHIiii", 0, rec["pos"], len(name), 255, 4680, len(rec["cigar"]), rec["flag"], len(seq), -1, -1, 0)
+    body += name + cigar + bytes(packed) + qual + tags
+    return struct.pack("<I", len(body)) + body
+
+
+def write_bam(path, records, ref_len, block=7000):
+    text = b"@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:ref\tLN:%d\n" % ref_len
+    raw = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", 1) + struct.pack("<I", 4) + b"ref\0" + struct.pack("<I", ref_len)
+    raw += b"".join(encode_record(r) for r in records)
+    with open(path, "wb") as f:
+        for o in range(0, len(raw), block):  # records straddle block borders on purpose
+            f.write(bgzf_block(raw[o:o + block]))
+        f.write(bgzf_block(b""))  # the BGZF end-of-file marker
+
+
+# ------------------------------------------------------------------------------------------------ generator
+def make_records(rng, ref, n, clean=False, rich=False):
+    recs = []
+    L = len(ref)
+    for r in range(n):
+        a = int(rng.integers(0, L - 30))
+        b = int(rng.integers(a + 20, L + 1))
+        if not clean and rng.random() < 0.5:
+            a, b = 0, L
+        cols = []  # (op, nt)
+        for c in range(a, b):
+            if c > a and rng.random() < 0.02:
+                for _ in range(int(rng.integers(1, 4))):
+                    cols.append(("I", "ACGT"[rng.integers(4)]))
+            u = rng.random()
+            if u < 0.02 and c > a and c < b - 1:
+                cols.append(("D", None))
+            elif not clean and u < 0.025 and c > a and c < b - 1:
+                cols.append(("N", None))
+            elif u < 0.05:
+                cols.append(("X", "ACGT".replace(ref[c], "")[rng.integers(3)]))
+            elif not clean and u < 0.06:
+                cols.append(("M", "N" if rng.random() < 0.3 else ref[c]))
+            else:
+                cols.append(("=", ref[c]))
+            if not clean and rng.random() < 0.004 and c < b - 1:
+                cols.append(("P", None))
+        if not clean and rng.random() < 0.4:
+            cols = [("S", "ACGT"[rng.integers(4)]) for _ in range(int(rng.integers(1, 9)))] + cols
+        if not clean and rng.random() < 0.4:
+            cols = cols + [("S", "ACGT"[rng.integers(4)]) for _ in range(int(rng.integers(1, 9)))]
+        cigar = []
+        for op, _ in cols:
+            if cigar and cigar[-1][0] == op:
+                cigar[-1][1] += 1
+            else:
+                cigar.append([op, 1])
+        if not clean and rng.random() < 0.2:
+            cigar = [["H", int(rng.integers(1, 50))]] + cigar + [["H", 3]]
+        seq = "".join(nt for _, nt in cols if nt is not None)
+        flag = 0
+        if rng.random() < 0.5:
+            flag |= 0x10
+        if not clean:
+            u = rng.random()
+            flag |= 0x100 if u < 0.05 else 0x800 if u < 0.10 else 0
+        qual = None if (not clean and rng.random() < 0.15) else [int(x) for x in rng.integers(0, 94, len(seq))]
+        tags = {"np": ("i", int(rng.integers(3, 40))), "rq": ("f", 0.999), "sn": ("B", ("S", [1, 2, 3, 4])), "zm": ("i", r)}
+        if rich and (clean or rng.random() < 0.8):
+            for t in ("dq", "iq", "sq"):
+                tags[t] = ("Z", "".join(chr(33 + int(x)) for x in rng.integers(0, 94, len(seq))))
+        tags["RG"] = ("Z", "abcd1234")
+        recs.append({"name": "movie/%d/ccs" % r, "flag": flag, "pos": a, "cigar": [tuple(x) for x in cigar], "seq": seq, "qual": qual,
+                     "tags": tags})
+    return recs
+
+
+# ------------------------------------------------------------------------------------------------ expectations
+def expected_reads(records, region_start, region_end):
+    """What BamToArrayReads makes of the records, from their per-column expansion (not the parser's walk)."""
+    lo, hi = max(region_start - 1, 0), max(region_end - 1, 0)
+    out = []
+    for rec in records:
+        if rec["flag"] & 0x900:
+            continue
+        ops = "".join(op * n for op, n in rec["cigar"])
+        ref_len = sum(ch in "MDN=X" for ch in ops)
+        start, end = rec["pos"], rec["pos"] + ref_len
+        if not (start < hi and end > lo):
+            continue
+        n = len(rec["seq"])
+        rich = all(t in rec["tags"] for t in ("sq", "dq", "iq"))
+        rev = bool(rec["flag"] & 0x10)
+
+        def tag(t):
+            v = [ord(ch) - 33 for ch in rec["tags"][t][1]]
+            return v[::-1] if rev else v
+        lanes = [rec["qual"] if rec["qual"] is not None else [0] * n]
+        if rich:
+            lanes += [tag("sq"), tag("dq"), tag("iq")]
+        c_lo, c_hi = max(start, lo), min(end, hi)
+        rp, qp = start, 0
+        cig, nuc, qs = [], [], [[] for _ in lanes]
+        for ch in ops:
+            ref_c, qry_c = ch in "MDN=X", ch in "MIS=X"
+            keep = ch not in "SH" and ((c_lo <= rp < c_hi) if ref_c else (c_lo <= rp <= c_hi))
+            if keep:
+                cig.append(ch)
+                nuc.append(rec["seq"][qp] if qry_c else ("*" if ch == "P" else "-"))
+                for k, lane in enumerate(lanes):
+                    qs[k].append(lane[qp] if qry_c else 0)
+            rp += ref_c
+            qp += qry_c
+        out.append((c_lo, c_hi, "".join(cig), "".join(nuc), qs, rec["name"]))
+    return out
+
+
+def run_bam_test(path, region_start, region_end, *extra):
+    assert os.path.exists(BIN), "tests/cpp/bam_test not built: run __graft_entry__.build()"
+    out = subprocess.run([BIN, path, str(region_start), str(region_end), *extra], capture_output=True, text=True, timeout=300)
+    reads, rest = [], []
+    for line in out.stdout.splitlines():
+        t = line.split(" ")
+        if t[0] == "READ":
+            k = t.index("NAME")
+            reads.append((int(t[1]), int(t[2]), t[3], t[4], [[int(x) for x in f.split(",")] if f else [] for f in t[5:k]], t[k + 1]))
+        else:
+            rest.append(line)
+    return out.returncode, reads, rest
+
+
+@pytest.fixture(scope="module")
+def ref():
+    rng = np.random.default_rng(5)
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, 420))
+
+
+@pytest.mark.parametrize("region", [(0, INT_MAX), (1, 421), (100, 200), (150, 151), (400, 5000), (0, 1), (2, 2)])
+@pytest.mark.parametrize("rich", [False, True])
+def test_records_become_array_reads(tmp_path, ref, region, rich):
+    rng = np.random.default_rng(11 + rich)
+    recs = make_records(rng, ref, 300, rich=rich)
+    path = str(tmp_path / "a.bam")
+    write_bam(path, recs, len(ref))
+    rc, got, _ = run_bam_test(path, *region)
+    assert rc == 0
+    want = expected_reads(recs, *region)
+    assert len(got) == len(want)
+    if region == (0, INT_MAX):
+        assert len(want) > 200 and any(len(w[4]) == 4 for w in want) == rich
+    for g, w in zip(got, want):
+        if not w[2]:  # nothing left inside the region: the dump cannot show which QV lanes the (absent) bases had
+            g, w = g[:4] + g[5:], w[:4] + w[5:]
+        assert g == w
+
+
+def test_block_sizes_and_threads(tmp_path, ref):
+    """Records straddling BGZF blocks of any size, one or many inflate threads: the same reads."""
+    rng = np.random.default_rng(3)
+    recs = make_records(rng, ref, 120, rich=True)
+    want = expected_reads(recs, 0, INT_MAX)
+    for block, threads in [(61, 1), (997, 3), (65000, 8), (4096, 16)]:
+        path = str(tmp_path / ("b%d.bam" % block))
+        write_bam(path, recs, len(ref), block=block)
+        rc, got, _ = run_bam_test(path, 0, INT_MAX, "--threads", str(threads))
+        assert rc == 0 and got == want
+
+
+def test_empty_and_broken_files(tmp_path, ref):
+    path = str(tmp_path / "e.bam")
+    write_bam(path, [], len(ref))
+    rc, got, _ = run_bam_test(path, 0, INT_MAX)
+    assert rc == 0 and got == []  # juliet then reports "Empty input." (src/tools/JulietWorkflow.cpp:139-142)
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(b"this is not a BGZF file at all........")
+    rc, got, rest = run_bam_test(bad, 0, INT_MAX)
+    assert rc == 1 and rest and rest[0].startswith("ERR ")
+    rng = np.random.default_rng(4)
+    write_bam(path, make_records(rng, ref, 20), len(ref))
+    data = open(path, "rb").read()
+    open(bad, "wb").write(data[:len(data) // 2])
+    rc, got, rest = run_bam_test(bad, 0, INT_MAX)
+    assert rc == 1 and rest[0].startswith("ERR ")
+    rc, got, rest = run_bam_test(str(tmp_path / "missing.bam"), 0, INT_MAX)
+    assert rc == 1 and "cannot open" in rest[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rich", [False, True])
+def test_bam_to_counts_matches_oracle(tmp_path, ref, rich):
+    """BAM -> ArrayReads -> MSAByRow/AminoAcidCaller on the GPU, against the oracle on the records themselves."""
+    rng = np.random.default_rng(21 + rich)
+    recs = make_records(rng, ref, 2500, clean=True, rich=rich)
+    path = str(tmp_path / "c.bam")
+    write_bam(path, recs, len(ref), block=60000)
+    region = (31, 391)
+    rc, got, rest = run_bam_test(path, *region, "--call")
+    assert rc == 0, rest[:3]
+    want = expected_reads(recs, *region)
+    assert got == want
+    rows = [(w[0], w[2], w[3]) + tuple(w[4]) for w in want]
+    reads = cases.make_reads(rows, rich=rich)
+    reads["ref_end"] = np.array([w[1] for w in want], dtype=np.int32)
+    m = orc.Msa(reads, (-1, -1, 42, -1))
+    nuc_lines = [l.split(" ") for l in rest if l.startswith("NUC ")]
+    begin = [l for l in rest if l.startswith("BEGIN ")][0].split(" ")
+    assert (int(begin[1]), int(begin[3])) == (m.begin1, m.end1)
+    assert (np.array([[int(x) for x in t[2:8]] for t in nuc_lines]) == m.nuc_counts()).all()
+    cod = m.codon_counts()
+    got_cod = {int(l.split(" ")[1]): {kv.split(":")[0]: int(kv.split(":")[1]) for kv in l.split(" ")[2:]} for l in rest if l.startswith("CODON ")}
+    for i in range(m.W):
+        assert got_cod.get(i, {}) == {pymodel.CODONS[k]: int(v) for k, v in enumerate(cod[i]) if v}, i
+    assert sum(len(v) for v in got_cod.values()) > 500
