@@ -119,6 +119,27 @@ int msq_reads_upload(msq_ctx* ctx, const msq_packed_reads* host_reads, msq_packe
 const msq_packed_reads* msq_packed_dev_view(const msq_packed_dev* p);
 int msq_packed_dev_free(msq_ctx* ctx, msq_packed_dev* p);
 
+/* One ArrayBase (include/pacbio/data/ArrayRead.h:96-119) as an 8-byte record: the boost::optional QVs become a
+ * presence byte + value.  has_qual covers qual; has_rich covers del, sub and ins (ArrayRead.h:98-101 sets all
+ * three or none). */
+typedef struct msq_array_base {
+    char cigar;       /* ArrayBase::Cigar */
+    char nucleotide;  /* ArrayBase::Nucleotide */
+    uint8_t has_qual, has_rich;
+    uint8_t qual, del, sub, ins;
+} msq_array_base;
+/* Device packer: MSAByRow::AddRead's per-base walk (src/MSA.cpp:144-186) over ArrayRead::Bases() on the GPU.
+ * bases[r] points at the n_bases[r] records of read r (host memory, one contiguous array per read: a
+ * std::vector<ArrayBase>'s data()).  The host only copies them into pinned staging (`threads` threads, <= 0 =
+ * up to 16; chunks of `chunk_bases` records, <= 0 = 32 Mi) while the previous chunk crosses PCIe; translation and
+ * bit-plane packing run on the device.  The result equals msq_pack_reads + msq_reads_upload of the same bases
+ * with absent QVs written as 255: same planes, NULL QV planes when no base of the set carries that QV (the QV
+ * bytes of slots that hold no base are unspecified).  Unknown cigar char: MSQ_ERR_CIGAR "Unexpected cigar <code>"
+ * for the first one in read order (src/MSA.cpp:182).  Synchronises. */
+int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                          const msq_array_base* const* bases, const int64_t* n_bases, int threads,
+                          int64_t chunk_bases, msq_packed_dev** out);
+
 /* ----------------------------------------------------------------------------------------------- pileup
  * MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:96-97,138-142): begin0 = min ReferenceStart,
  * end0 = max ReferenceEnd (0-based; MSAByRow::BeginPos()/EndPos() report begin0+1 / end0+1, MSA.cpp:107-108).

@@ -22,6 +22,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -29,6 +30,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "msq_front.hpp"
@@ -165,114 +167,245 @@ public:
         : Data::ArrayRead(idx, name, referenceStart, referenceEnd, std::move(bases)), chemistry_(std::move(chemistry))
     {
     }
+    /// The reference returns pbbam's chemistry name for the record's read group (src/ArrayRead.cpp:101-104); juliet
+    /// only compares these strings between reads and warns on two names (src/tools/JulietWorkflow.cpp:144-148,
+    /// src/ErrorEstimates.cpp:50).  pbbam's kit table is not in the reference tree, so this is the read group's
+    /// "BINDINGKIT/SEQUENCINGKIT/BASECALLERVERSION" triple as written in its @RG DS field ("" without one): equal
+    /// whenever pbbam's names are equal for one triple, never translated to a marketing name.
     std::string SequencingChemistry() const override { return chemistry_; }
 
 private:
     std::string chemistry_;
 };
 
+struct BamTimings  // seconds, for tools and benches
+{
+    double read = 0, inflate = 0, index = 0, parse = 0;
+    size_t file_bytes = 0, bam_bytes = 0, records = 0, kept = 0;
+};
+
 struct BamUtils
 {
     /// src/BamUtils.cpp:56-78.  regionStart / regionEnd as juliet passes them (1-based; its defaults are 0 and
-    /// INT_MAX, include/pacbio/juliet/JulietSettings.h:73-74).
+    /// INT_MAX, include/pacbio/juliet/JulietSettings.h:73-74).  Blocks are inflated and records decoded on `threads`
+    /// host threads; the result is in file order with idx 0, 1, ... over the kept records, as in the reference.
     static std::vector<std::shared_ptr<Data::ArrayRead>> BamToArrayReads(const std::string& filePath, int regionStart,
                                                                         int regionEnd,
-                                                                        unsigned threads = std::thread::hardware_concurrency())
+                                                                        unsigned threads = std::thread::hardware_concurrency(),
+                                                                        BamTimings* timings = nullptr)
     {
         using namespace detail;
-        std::vector<std::shared_ptr<Data::ArrayRead>> returnList;
+        using Clock = std::chrono::steady_clock;
+        auto secs = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        if (threads == 0) threads = 1;
         regionStart = std::max(regionStart - 1, 0);
         regionEnd = std::max(regionEnd - 1, 0);
-        const std::vector<uint8_t> data = InflateBgzf(ReadFile(filePath), threads ? threads : 1);
+        const auto t0 = Clock::now();
+        std::vector<uint8_t> file = ReadFile(filePath);
+        const auto t1 = Clock::now();
+        const std::vector<uint8_t> data = InflateBgzf(file, threads);
+        const size_t file_bytes = file.size();
+        std::vector<uint8_t>().swap(file);
+        const auto t2 = Clock::now();
         if (data.size() < 12 || std::memcmp(data.data(), "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file: " + filePath);
         size_t off = 4;
         const size_t l_text = U32(&data[off]);
+        if (off + 4 + l_text + 4 > data.size()) throw std::runtime_error("truncated BAM header");
+        const std::vector<std::pair<std::string, std::string>> readGroups =
+            ReadGroupChemistries(std::string(reinterpret_cast<const char*>(&data[off + 4]), l_text));
         off += 4 + l_text;
         const size_t n_ref = U32(&data[off]);
         off += 4;
         for (size_t r = 0; r < n_ref; ++r) {
+            if (off + 4 > data.size()) throw std::runtime_error("truncated BAM header");
             const size_t l_name = U32(&data[off]);
             off += 4 + l_name + 4;
         }
-        static const char kSeq[] = "=ACMGRSVTWYHKDBN";
-        static const char kOps[] = "MIDNSHP=X";
-        int idx = 0;
+        // pass 1 (cheap, sequential): record offsets, filters, idx of the kept ones
+        struct Kept
+        {
+            size_t off;  // of the record body
+            size_t block_size;
+            int64_t ref_start, ref_end;
+        };
+        std::vector<Kept> kept;
+        size_t n_records = 0;
         while (off + 4 <= data.size()) {
             const size_t block_size = U32(&data[off]);
             const uint8_t* rec = &data[off + 4];
+            const size_t body = off + 4;
             off += 4 + block_size;
-            if (off > data.size()) throw std::runtime_error("truncated BAM record");
-            const int32_t pos = I32(rec + 4);
+            if (off > data.size() || block_size < 32) throw std::runtime_error("truncated BAM record");
+            ++n_records;
             const size_t l_read_name = rec[8];
             const size_t n_cigar = U16(rec + 12);
             const uint16_t flag = U16(rec + 14);
             const size_t l_seq = U32(rec + 16);
-            if (flag & 0x800) continue;  // IsSupplementaryAlignment
-            if (flag & 0x100) continue;  // !IsPrimaryAlignment
-            if (flag & 0x4) continue;    // unmapped: no reference interval
-            const uint8_t* name = rec + 32;
-            const uint8_t* cigar = name + l_read_name;
-            const uint8_t* seq = cigar + 4 * n_cigar;
-            const uint8_t* qual = seq + (l_seq + 1) / 2;
-            const uint8_t* tags = qual + l_seq;
-            const uint8_t* end = rec + block_size;
-            // reference span
+            if (32 + l_read_name + 4 * n_cigar + (l_seq + 1) / 2 + l_seq > block_size) throw std::runtime_error("malformed BAM record");
+            if (flag & 0x800) continue;  // IsSupplementaryAlignment (BamUtils.cpp:69)
+            if (flag & 0x100) continue;  // !IsPrimaryAlignment (BamUtils.cpp:70)
+            if (flag & 0x4) continue;    // unmapped: no reference interval to overlap
+            const uint8_t* cigar = rec + 32 + l_read_name;
             int64_t ref_len = 0;
             for (size_t k = 0; k < n_cigar; ++k) {
                 const uint32_t c = U32(cigar + 4 * k);
                 const int op = c & 15;
                 if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
             }
-            const int64_t ref_start = pos, ref_end = pos + ref_len;
+            const int64_t ref_start = I32(rec + 4), ref_end = ref_start + ref_len;
             if (!(ref_start < regionEnd && ref_end > regionStart)) continue;  // BamUtils.cpp:71
-            const bool hasQual = l_seq > 0 && qual[0] != 0xFF;
-            const uint8_t *sq = nullptr, *dq = nullptr, *iq = nullptr;
-            size_t nsq = 0, ndq = 0, niq = 0;
-            const bool rich = FindZTag(tags, end, 's', 'q', &sq, &nsq) && FindZTag(tags, end, 'd', 'q', &dq, &ndq) &&
-                              FindZTag(tags, end, 'i', 'q', &iq, &niq) && nsq == l_seq && ndq == l_seq && niq == l_seq;
-            const bool reverse = flag & 0x10;
-            auto tagQv = [&](const uint8_t* t, size_t q) -> uint8_t {  // tags are native-oriented; SEQ / QUAL genomic
-                const size_t i = reverse ? l_seq - 1 - q : q;
-                return (uint8_t)(t[i] - 33);
-            };
-            // walk the alignment, clipped to [regionStart, regionEnd)
-            const int64_t clip_lo = std::max<int64_t>(ref_start, regionStart), clip_hi = std::min<int64_t>(ref_end, regionEnd);
-            std::vector<Data::ArrayBase> bases;
-            int64_t rp = ref_start;
-            size_t qp = 0;
-            auto emit = [&](char op, char nt, bool has_query, size_t q) {
-                const uint8_t qv = has_query ? (hasQual ? qual[q] : 0) : 0;
-                if (rich)
-                    bases.emplace_back(op, nt, qv, has_query ? tagQv(sq, q) : 0, has_query ? tagQv(dq, q) : 0,
-                                       has_query ? tagQv(iq, q) : 0);
-                else
-                    bases.emplace_back(op, nt, qv);  // a record without QUAL: QualQV 0 (ArrayRead.cpp:94-96)
-            };
-            for (size_t k = 0; k < n_cigar; ++k) {
-                const uint32_t c = U32(cigar + 4 * k);
-                const int op = c & 15;
-                const size_t len = c >> 4;
-                if (op > 8) throw std::runtime_error("bad CIGAR op in " + filePath);
-                const bool cons_ref = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
-                const bool cons_query = op == 0 || op == 1 || op == 4 || op == 7 || op == 8;
-                for (size_t i = 0; i < len; ++i) {
-                    const bool inside = cons_ref ? (rp >= clip_lo && rp < clip_hi) : (rp >= clip_lo && rp <= clip_hi);
-                    if (inside && op != 4 && op != 5) {  // clips are excised
-                        if (cons_query) {
-                            const char nt = kSeq[(seq[qp >> 1] >> ((qp & 1) ? 0 : 4)) & 15];
-                            emit(kOps[op], nt, true, qp);
-                        } else {
-                            emit(kOps[op], op == 6 ? '*' : '-', false, 0);
-                        }
+            kept.push_back({body, block_size, ref_start, ref_end});
+        }
+        const auto t3 = Clock::now();
+        // pass 2 (parallel): one ArrayRead per kept record
+        std::vector<std::shared_ptr<Data::ArrayRead>> returnList(kept.size());
+        auto parse = [&](size_t first, size_t last) {
+            for (size_t i = first; i < last; ++i)
+                returnList[i] = DecodeRecord(&data[kept[i].off], kept[i].block_size, kept[i].ref_start, kept[i].ref_end, regionStart,
+                                             regionEnd, (int)i, readGroups, filePath);
+        };
+        const unsigned workers = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, kept.size() / 64 + 1));
+        if (workers == 1) {
+            parse(0, kept.size());
+        } else {
+            std::vector<std::thread> pool;
+            std::vector<std::string> errors(workers);
+            for (unsigned t = 0; t < workers; ++t)
+                pool.emplace_back([&, t] {
+                    try {
+                        parse(kept.size() * t / workers, kept.size() * (t + 1) / workers);
+                    } catch (const std::exception& e) {
+                        errors[t] = e.what();
                     }
-                    if (cons_ref) ++rp;
-                    if (cons_query) ++qp;
-                }
-            }
-            returnList.emplace_back(std::make_shared<BAMArrayRead>(idx++, std::string(reinterpret_cast<const char*>(name)),
-                                                                   (size_t)clip_lo, (size_t)clip_hi, std::move(bases)));
+                });
+            for (auto& th : pool) th.join();
+            for (const auto& e : errors)
+                if (!e.empty()) throw std::runtime_error(e);
+        }
+        const auto t4 = Clock::now();
+        if (timings) {
+            timings->read = secs(t0, t1);
+            timings->inflate = secs(t1, t2);
+            timings->index = secs(t2, t3);
+            timings->parse = secs(t3, t4);
+            timings->file_bytes = file_bytes;
+            timings->bam_bytes = data.size();
+            timings->records = n_records;
+            timings->kept = kept.size();
         }
         return returnList;
+    }
+
+private:
+    /// (@RG ID, "BINDINGKIT/SEQUENCINGKIT/BASECALLERVERSION") of every read group in the header text
+    static std::vector<std::pair<std::string, std::string>> ReadGroupChemistries(const std::string& text)
+    {
+        std::vector<std::pair<std::string, std::string>> out;
+        size_t p = 0;
+        while (p < text.size()) {
+            size_t e = text.find('\n', p);
+            if (e == std::string::npos) e = text.size();
+            if (text.compare(p, 4, "@RG\t") == 0) {
+                std::string id, ds;
+                size_t f = p + 4;
+                while (f < e) {
+                    size_t g = text.find('\t', f);
+                    if (g == std::string::npos || g > e) g = e;
+                    if (text.compare(f, 3, "ID:") == 0) id = text.substr(f + 3, g - f - 3);
+                    if (text.compare(f, 3, "DS:") == 0) ds = text.substr(f + 3, g - f - 3);
+                    f = g + 1;
+                }
+                std::string kit[3];
+                static const char* const keys[3] = {"BINDINGKIT=", "SEQUENCINGKIT=", "BASECALLERVERSION="};
+                size_t q = 0;
+                while (q < ds.size()) {
+                    size_t h = ds.find(';', q);
+                    if (h == std::string::npos) h = ds.size();
+                    for (int k = 0; k < 3; ++k)
+                        if (ds.compare(q, std::strlen(keys[k]), keys[k]) == 0) kit[k] = ds.substr(q + std::strlen(keys[k]), h - q - std::strlen(keys[k]));
+                    q = h + 1;
+                }
+                const bool any = !kit[0].empty() || !kit[1].empty() || !kit[2].empty();
+                out.emplace_back(id, any ? kit[0] + "/" + kit[1] + "/" + kit[2] : std::string());
+            }
+            p = e + 1;
+        }
+        return out;
+    }
+
+    static std::shared_ptr<Data::ArrayRead> DecodeRecord(const uint8_t* rec, size_t block_size, int64_t ref_start, int64_t ref_end,
+                                                         int regionStart, int regionEnd, int idx,
+                                                         const std::vector<std::pair<std::string, std::string>>& readGroups,
+                                                         const std::string& filePath)
+    {
+        using namespace detail;
+        static const char kSeq[] = "=ACMGRSVTWYHKDBN";
+        static const char kOps[] = "MIDNSHP=X";
+        const size_t l_read_name = rec[8];
+        const size_t n_cigar = U16(rec + 12);
+        const uint16_t flag = U16(rec + 14);
+        const size_t l_seq = U32(rec + 16);
+        const uint8_t* name = rec + 32;
+        const uint8_t* cigar = name + l_read_name;
+        const uint8_t* seq = cigar + 4 * n_cigar;
+        const uint8_t* qual = seq + (l_seq + 1) / 2;
+        const uint8_t* tags = qual + l_seq;
+        const uint8_t* end = rec + block_size;
+        const bool hasQual = l_seq > 0 && qual[0] != 0xFF;
+        const uint8_t *sq = nullptr, *dq = nullptr, *iq = nullptr, *rg = nullptr;
+        size_t nsq = 0, ndq = 0, niq = 0, nrg = 0;
+        const bool rich = FindZTag(tags, end, 's', 'q', &sq, &nsq) && FindZTag(tags, end, 'd', 'q', &dq, &ndq) &&
+                          FindZTag(tags, end, 'i', 'q', &iq, &niq) && nsq == l_seq && ndq == l_seq && niq == l_seq;
+        std::string chemistry;
+        if (FindZTag(tags, end, 'R', 'G', &rg, &nrg)) {
+            const std::string id(reinterpret_cast<const char*>(rg), nrg);
+            for (const auto& g : readGroups)
+                if (g.first == id) chemistry = g.second;
+        }
+        const bool reverse = flag & 0x10;
+        auto tagQv = [&](const uint8_t* t, size_t q) -> uint8_t {  // tags are native-oriented; SEQ / QUAL genomic
+            const size_t i = reverse ? l_seq - 1 - q : q;
+            return (uint8_t)(t[i] - 33);
+        };
+        // walk the alignment, clipped to [regionStart, regionEnd)
+        const int64_t clip_lo = std::max<int64_t>(ref_start, regionStart), clip_hi = std::min<int64_t>(ref_end, regionEnd);
+        std::vector<Data::ArrayBase> bases;
+        bases.reserve((size_t)(clip_hi - clip_lo) + 16);
+        int64_t rp = ref_start;
+        size_t qp = 0;
+        auto emit = [&](char op, char nt, bool has_query, size_t q) {
+            const uint8_t qv = has_query ? (hasQual ? qual[q] : 0) : 0;
+            if (rich)
+                bases.emplace_back(op, nt, qv, has_query ? tagQv(sq, q) : 0, has_query ? tagQv(dq, q) : 0, has_query ? tagQv(iq, q) : 0);
+            else
+                bases.emplace_back(op, nt, qv);  // a record without QUAL: QualQV 0 (ArrayRead.cpp:94-96)
+        };
+        for (size_t k = 0; k < n_cigar; ++k) {
+            const uint32_t c = U32(cigar + 4 * k);
+            const int op = c & 15;
+            const size_t len = c >> 4;
+            if (op > 8) throw std::runtime_error("bad CIGAR op in " + filePath);
+            const bool cons_ref = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
+            const bool cons_query = op == 0 || op == 1 || op == 4 || op == 7 || op == 8;
+            if (cons_query && qp + len > l_seq) throw std::runtime_error("CIGAR longer than SEQ in " + filePath);
+            if (op == 4 || op == 5) {  // clips are excised
+                if (cons_query) qp += len;
+                continue;
+            }
+            for (size_t i = 0; i < len; ++i) {
+                const bool inside = cons_ref ? (rp >= clip_lo && rp < clip_hi) : (rp >= clip_lo && rp <= clip_hi);
+                if (inside) {
+                    if (cons_query)
+                        emit(kOps[op], kSeq[(seq[qp >> 1] >> ((qp & 1) ? 0 : 4)) & 15], true, qp);
+                    else
+                        emit(kOps[op], op == 6 ? '*' : '-', false, 0);
+                }
+                if (cons_ref) ++rp;
+                if (cons_query) ++qp;
+            }
+        }
+        return std::make_shared<BAMArrayRead>(idx, std::string(reinterpret_cast<const char*>(name)), (size_t)clip_lo, (size_t)clip_hi,
+                                              std::move(bases), std::move(chemistry));
     }
 };
 }  // namespace IO

@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <limits>
 #include <map>
@@ -246,43 +247,32 @@ private:
         const QvThresholds qv;  // member qvThresholds_ of the reference: read from the environment per MSA (MSA.h:82)
         numReads_ = reads.size();
         for (const auto* r : reads) names_.push_back(r->Name());
-        // flat ArrayBase columns
+        // the reads' ArrayBase arrays go to the GPU as they are (8-byte records); msq_pack_reads_device copies them
+        // through pinned staging and translates / packs them on the device
+        static_assert(sizeof(ArrayBase) == sizeof(msq_array_base) && offsetof(ArrayBase, Cigar) == offsetof(msq_array_base, cigar) &&
+                          offsetof(ArrayBase, Nucleotide) == offsetof(msq_array_base, nucleotide) &&
+                          offsetof(ArrayBase, HasQualQV) == offsetof(msq_array_base, has_qual) &&
+                          offsetof(ArrayBase, HasRichQVs) == offsetof(msq_array_base, has_rich) &&
+                          offsetof(ArrayBase, QualQV) == offsetof(msq_array_base, qual) && offsetof(ArrayBase, DelQV) == offsetof(msq_array_base, del) &&
+                          offsetof(ArrayBase, SubQV) == offsetof(msq_array_base, sub) && offsetof(ArrayBase, InsQV) == offsetof(msq_array_base, ins),
+                      "ArrayBase is the ABI's msq_array_base");
         std::vector<int32_t> rs, re;
-        std::vector<int64_t> off{0};
-        std::vector<char> cigar, nuc;
-        std::vector<uint8_t> qual, sub, del, ins;
-        bool anyQual = false, anyRich = false;
-        for (const auto* r : reads)
-            for (const auto& b : r->Bases()) {
-                anyQual = anyQual || b.HasQualQV;
-                anyRich = anyRich || b.HasRichQVs;
-            }
+        std::vector<const msq_array_base*> ptr;
+        std::vector<int64_t> len;
+        rs.reserve(reads.size());
+        re.reserve(reads.size());
+        ptr.reserve(reads.size());
+        len.reserve(reads.size());
         for (const auto* r : reads) {
             rs.push_back(r->ReferenceStart());
             re.push_back(r->ReferenceEnd());
-            for (const auto& b : r->Bases()) {
-                cigar.push_back(b.Cigar);
-                nuc.push_back(b.Nucleotide);
-                // an absent QV always passes (ArrayRead.inl:72-87): 255 passes every threshold
-                if (anyQual) qual.push_back(b.HasQualQV ? b.QualQV : 255);
-                if (anyRich) {
-                    sub.push_back(b.HasRichQVs ? b.SubQV : 255);
-                    del.push_back(b.HasRichQVs ? b.DelQV : 255);
-                    ins.push_back(b.HasRichQVs ? b.InsQV : 255);
-                }
-            }
-            off.push_back(static_cast<int64_t>(cigar.size()));
+            ptr.push_back(reinterpret_cast<const msq_array_base*>(r->Bases().data()));
+            len.push_back(static_cast<int64_t>(r->Bases().size()));
         }
-        msq_packed_host* packed = nullptr;
-        int rc = msq_pack_reads(reads.size(), rs.data(), re.data(), off.data(), cigar.data(), nuc.data(),
-                                anyQual ? qual.data() : nullptr, anyRich ? sub.data() : nullptr,
-                                anyRich ? del.data() : nullptr, anyRich ? ins.data() : nullptr, &packed);
-        Msq::Check(rc);  // "Unexpected cigar ..." -> std::runtime_error
         msq_ctx* ctx = Msq::Context();
         msq_packed_dev* dev = nullptr;
-        rc = msq_reads_upload(ctx, msq_packed_host_view(packed), &dev);
-        msq_packed_host_free(packed);
-        Msq::Check(rc);
+        // "Unexpected cigar ..." -> std::runtime_error
+        Msq::Check(msq_pack_reads_device(ctx, reads.size(), rs.data(), re.data(), ptr.data(), len.data(), 0, 0, &dev));
         dev_.reset(dev, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // kept for PhaseKeys
         {
             int32_t b0 = 0, e0 = 0;

@@ -60,6 +60,10 @@ extern "C" int msq_ctx_destroy(msq_ctx* ctx)
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_lfact) (void)hipFree(ctx->d_lfact);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
+        if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);
+    }
     timing_release(ctx);
     delete ctx;
     return MSQ_OK;

@@ -28,6 +28,10 @@ struct msq_ctx {
     // scratch owned by the context, grown on demand
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    // pinned host staging of the device packer (msq_pack_reads_device): two buffers, reused across calls
+    void* h_stage[2] = {nullptr, nullptr};
+    size_t h_stage_bytes = 0;
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
     // measurement aid: event pairs around the dominant pileup kernel (msq_timing_enable)
     std::vector<hipEvent_t> ev_begin, ev_end;
     int ev_used = 0;

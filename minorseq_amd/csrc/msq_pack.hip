@@ -2,7 +2,10 @@
 // Format: include/msq_abi.h "packed read format".
 #include "msq_internal.h"
 
+#include <algorithm>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 struct msq_packed_host {
@@ -20,7 +23,7 @@ struct msq_packed_dev {
 
 // Per-base translation of (ArrayBase::Cigar, ArrayBase::Nucleotide) as MSAByRow::AddRead switches on
 // them (src/MSA.cpp:158-184).  Returns false on an unknown cigar char ("Unexpected cigar", :182).
-static inline bool encode_base(char cigar, char nuc, unsigned* op, unsigned* code, bool* exotic)
+static inline __host__ __device__ bool encode_base(char cigar, char nuc, unsigned* op, unsigned* code, bool* exotic)
 {
     switch (cigar) {
         case '=':
@@ -191,5 +194,251 @@ extern "C" int msq_packed_dev_free(msq_ctx* ctx, msq_packed_dev* p)
     for (int j = 0; j < 8; ++j)
         if (p->ptrs[j]) (void)hipFree(p->ptrs[j]);
     delete p;
+    return MSQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------ device packer
+// msq_pack_reads_device: the same packed bytes as msq_pack_reads + msq_reads_upload, but the host only copies each
+// read's msq_array_base records (the front's ArrayBase, 8 bytes) into pinned staging -- on several threads, chunk by
+// chunk, overlapped with the previous chunk's H2D copy -- and the per-base translation (MSAByRow::AddRead's switch,
+// src/MSA.cpp:158-184) and the bit-plane packing run on the GPU: one half-wave per 32-base group.
+__global__ __launch_bounds__(256) void pack_groups_kernel(const uint64_t* __restrict__ stage, uint64_t chunk_base0,
+                                                          const uint64_t* __restrict__ base_off, const uint64_t* __restrict__ group_off,
+                                                          uint64_t r0, uint64_t r1, uint64_t g0, uint64_t g1, uint4* __restrict__ bop,
+                                                          uint8_t* __restrict__ q_qual, uint8_t* __restrict__ q_del,
+                                                          uint8_t* __restrict__ q_sub, uint8_t* __restrict__ q_ins,
+                                                          unsigned long long* __restrict__ err, uint32_t* __restrict__ flags)
+{
+    __shared__ uint8_t nib[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, k = lane & 31;
+    const uint64_t g = g0 + ((uint64_t)blockIdx.x * 4 + wave) * 2 + h;
+    const bool valid_g = g < g1;
+    const uint64_t gs = valid_g ? g : g1 - 1;
+    uint64_t lo = r0, hi = r1;  // the read of this group: the last r in [r0, r1) with group_off[r] <= gs
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (group_off[mid] <= gs)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint64_t b0 = base_off[lo], len = base_off[lo + 1] - b0;
+    const uint64_t i = (gs - group_off[lo]) * 32 + (uint64_t)k;
+    const bool has = valid_g && i < len;
+    const uint64_t w = has ? stage[b0 - chunk_base0 + i] : 0;  // {Cigar, Nucleotide, HasQualQV, HasRichQVs, QualQV, DelQV, SubQV, InsQV}
+    unsigned op = 3, code = 0;
+    bool exotic = false;
+    if (has && !encode_base((char)(w & 0xff), (char)((w >> 8) & 0xff), &op, &code, &exotic)) {
+        atomicMin(err, (unsigned long long)(((b0 + i) << 8) | (w & 0xff)));  // the first one in read order is reported
+        op = 3;
+        code = 0;
+    }
+    if (exotic) atomicOr(flags, MSQ_READS_HAS_EXOTIC);
+    // normalized layout: consuming bases from slot 0 up, the others from 31 down, both in genomic order
+    const bool cons = has && op < 2, ncons = has && op >= 2;
+    const uint32_t hc = (uint32_t)(__ballot(cons) >> (32 * h)), hn = (uint32_t)(__ballot(ncons) >> (32 * h));
+    const uint32_t below = (1u << k) - 1u;
+    const int slot = cons ? __popc(hc & below) : 31 - __popc(hn & below);
+    nib[wave][lane] = 12;  // padding: op 3
+    __syncthreads();
+    if (has) nib[wave][h * 32 + slot] = (uint8_t)(code | (op << 2));
+    __syncthreads();
+    const unsigned v = nib[wave][lane];
+    const uint64_t p0 = __ballot(v & 1u), p1 = __ballot(v & 2u), p2 = __ballot(v & 4u), p3 = __ballot(v & 8u);
+    if (k == 0 && valid_g) bop[g] = make_uint4((uint32_t)(p0 >> (32 * h)), (uint32_t)(p1 >> (32 * h)), (uint32_t)(p2 >> (32 * h)), (uint32_t)(p3 >> (32 * h)));
+    if (has) {  // an absent QV always passes (ArrayRead.inl:72-87): 255 passes every threshold
+        const uint64_t at = g * 32 + (uint64_t)MSQ_QV_BYTE(slot);
+        const bool hq = (w >> 16) & 0xff, hr = (w >> 24) & 0xff;
+        if (q_qual) q_qual[at] = hq ? (uint8_t)(w >> 32) : (uint8_t)255;
+        if (q_del) q_del[at] = hr ? (uint8_t)(w >> 40) : (uint8_t)255;
+        if (q_sub) q_sub[at] = hr ? (uint8_t)(w >> 48) : (uint8_t)255;
+        if (q_ins) q_ins[at] = hr ? (uint8_t)(w >> 56) : (uint8_t)255;
+    }
+}
+
+// memcpy of n records that also ORs them together (the HasQualQV / HasRichQVs bytes decide which planes exist)
+static uint64_t copy_or(uint64_t* dst, const msq_array_base* src, int64_t n)
+{
+    uint64_t acc = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t w;
+        std::memcpy(&w, src + i, 8);
+        acc |= w;
+        dst[i] = w;
+    }
+    return acc;
+}
+
+static void free_packed_dev(msq_packed_dev* d)
+{
+    for (int j = 0; j < 8; ++j)
+        if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
+    delete d;
+}
+
+extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                     const msq_array_base* const* bases, const int64_t* n_bases, int threads,
+                                     int64_t chunk_bases, msq_packed_dev** out)
+{
+    static_assert(sizeof(msq_array_base) == 8, "msq_array_base is one 8-byte record");
+    if (!ctx || !out) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL argument");
+    *out = nullptr;
+    if (n_reads && (!ref_start || !ref_end || !bases || !n_bases)) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL array");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    std::vector<uint64_t> base_off, group_off;
+    int64_t longest = 0;
+    try {
+        base_off.resize(n_reads + 1);
+        group_off.resize(n_reads + 1);
+    } catch (const std::bad_alloc&) {
+        return msq_fail(MSQ_ERR_NOMEM, "msq_pack_reads_device: out of memory");
+    }
+    base_off[0] = group_off[0] = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        if (n_bases[r] < 0 || (n_bases[r] > 0 && !bases[r])) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: bad read %llu", (unsigned long long)r);
+        base_off[r + 1] = base_off[r] + (uint64_t)n_bases[r];
+        group_off[r + 1] = group_off[r] + (uint64_t)(n_bases[r] + 31) / 32;
+        longest = std::max(longest, n_bases[r]);
+    }
+    const uint64_t total_bases = base_off[n_reads], n_groups = group_off[n_reads];
+    uint64_t cap = chunk_bases > 0 ? (uint64_t)chunk_bases : (uint64_t)32 << 20;  // records per chunk (256 MB)
+    cap = std::max<uint64_t>(std::min(cap, total_bases), (uint64_t)longest);
+    const size_t stage_bytes = std::max<size_t>(cap * 8, 64);
+    unsigned n_thr = threads > 0 ? (unsigned)threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+
+    // staging: two pinned host buffers (kept by the context), one device buffer + the error words in the scratch
+    if (ctx->h_stage_bytes < stage_bytes) {
+        MSQ_HIP(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 2; ++k) {
+            if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
+            ctx->h_stage[k] = nullptr;
+        }
+        ctx->h_stage_bytes = 0;
+        const size_t want = stage_bytes + (stage_bytes >> 3);
+        for (int k = 0; k < 2; ++k) {
+            hipError_t e = hipHostMalloc(&ctx->h_stage[k], want, hipHostMallocDefault);
+            if (e != hipSuccess) return msq_fail(MSQ_ERR_NOMEM, "msq_pack_reads_device: hipHostMalloc(%zu): %s", want, hipGetErrorString(e));
+        }
+        ctx->h_stage_bytes = want;
+    }
+    for (int k = 0; k < 2; ++k)
+        if (!ctx->stage_done[k]) MSQ_HIP(hipEventCreateWithFlags(&ctx->stage_done[k], hipEventDisableTiming));
+    void* scratch = nullptr;
+    int rc = msq_scratch(ctx, 256 + stage_bytes, &scratch);
+    if (rc != MSQ_OK) return rc;
+    unsigned long long* d_errword = (unsigned long long*)scratch;
+    uint32_t* d_flags = (uint32_t*)((char*)scratch + 8);
+    uint64_t* d_stage = (uint64_t*)((char*)scratch + 256);
+    MSQ_HIP(hipMemsetAsync(scratch, 0xFF, 8, ctx->stream));
+    MSQ_HIP(hipMemsetAsync(d_flags, 0, 8, ctx->stream));
+
+    msq_packed_dev* d = new (std::nothrow) msq_packed_dev;
+    if (!d) return msq_fail(MSQ_ERR_NOMEM, "msq_pack_reads_device: out of memory");
+    void* d_base_off = nullptr;
+    auto fail = [&](int code, const char* what, hipError_t e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        if (d_base_off) (void)hipFree(d_base_off);
+        free_packed_dev(d);
+        return msq_fail(code, "msq_pack_reads_device: %s: %s", what, hipGetErrorString(e));
+    };
+    {
+        const void* src[4] = {ref_start, ref_end, group_off.data(), nullptr};
+        const size_t bytes[4] = {n_reads * 4, n_reads * 4, (n_reads + 1) * 8, n_groups * 16};
+        for (int k = 0; k < 4; ++k) {
+            hipError_t e = hipMalloc(&d->ptrs[k], bytes[k] ? bytes[k] : 16);
+            if (e == hipSuccess && bytes[k] && src[k]) e = hipMemcpyAsync(d->ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "read tables", e);
+        }
+        hipError_t e = hipMalloc(&d_base_off, (n_reads + 1) * 8);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_base_off, base_off.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "base offsets", e);
+    }
+
+    uint64_t r0 = 0;
+    for (int chunk = 0; r0 < n_reads; ++chunk) {
+        uint64_t r1 = r0 + 1;  // at least one read; cap >= the longest read
+        while (r1 < n_reads && base_off[r1 + 1] - base_off[r0] <= cap) ++r1;
+        const uint64_t cb = base_off[r1] - base_off[r0];
+        const int b = chunk & 1;
+        if (chunk >= 2) {
+            hipError_t e = hipEventSynchronize(ctx->stage_done[b]);  // the copy that last read this pinned buffer
+            if (e != hipSuccess) return fail(MSQ_ERR_HIP, "hipEventSynchronize", e);
+        }
+        uint64_t* hs = (uint64_t*)ctx->h_stage[b];
+        uint64_t any = 0;
+        const unsigned workers = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_thr, cb >> 17));  // >= 1 MB each
+        if (workers == 1) {
+            for (uint64_t r = r0; r < r1; ++r) any |= copy_or(hs + (base_off[r] - base_off[r0]), bases[r], n_bases[r]);
+        } else {
+            std::vector<uint64_t> ors(workers, 0);
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < workers; ++t) {
+                // reads whose first base falls into this worker's share of the chunk's bases
+                const uint64_t lo_b = base_off[r0] + cb * t / workers, hi_b = base_off[r0] + cb * (t + 1) / workers;
+                const uint64_t ra = std::lower_bound(base_off.begin() + r0, base_off.begin() + r1, lo_b) - base_off.begin();
+                const uint64_t rb = t + 1 == workers ? r1 : std::lower_bound(base_off.begin() + r0, base_off.begin() + r1, hi_b) - base_off.begin();
+                pool.emplace_back([&, t, ra, rb] {
+                    uint64_t acc = 0;
+                    for (uint64_t r = ra; r < rb; ++r) acc |= copy_or(hs + (base_off[r] - base_off[r0]), bases[r], n_bases[r]);
+                    ors[t] = acc;
+                });
+            }
+            for (auto& th : pool) th.join();
+            for (uint64_t o : ors) any |= o;
+        }
+        // QV planes appear with the first chunk that carries the QV; every base before it lacked it -> 255
+        const bool want[4] = {((any >> 16) & 0xff) != 0, ((any >> 24) & 0xff) != 0, ((any >> 24) & 0xff) != 0, ((any >> 24) & 0xff) != 0};
+        for (int q = 0; q < 4; ++q)
+            if (want[q] && !d->ptrs[4 + q]) {
+                hipError_t e = hipMalloc(&d->ptrs[4 + q], n_groups * 32 ? n_groups * 32 : 16);
+                if (e == hipSuccess && group_off[r0]) e = hipMemsetAsync(d->ptrs[4 + q], 0xFF, group_off[r0] * 32, ctx->stream);
+                if (e == hipSuccess && n_groups > group_off[r0])
+                    e = hipMemsetAsync((char*)d->ptrs[4 + q] + group_off[r0] * 32, 0, (n_groups - group_off[r0]) * 32, ctx->stream);
+                if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "QV plane", e);
+            }
+        if (cb) {
+            hipError_t e = hipMemcpyAsync(d_stage, hs, cb * 8, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->stage_done[b], ctx->stream);
+            if (e != hipSuccess) return fail(MSQ_ERR_HIP, "staging copy", e);
+            const uint64_t g0 = group_off[r0], g1 = group_off[r1];
+            const uint64_t blocks = (g1 - g0 + 7) / 8;  // 4 waves x 2 groups
+            hipLaunchKernelGGL(pack_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_stage, base_off[r0],
+                               (const uint64_t*)d_base_off, (const uint64_t*)d->ptrs[2], r0, r1, g0, g1, (uint4*)d->ptrs[3],
+                               (uint8_t*)d->ptrs[4], (uint8_t*)d->ptrs[5], (uint8_t*)d->ptrs[6], (uint8_t*)d->ptrs[7], d_errword, d_flags);
+            e = hipGetLastError();
+            if (e != hipSuccess) return fail(MSQ_ERR_HIP, "pack kernel", e);
+        } else if (chunk >= 0) {
+            hipError_t e = hipEventRecord(ctx->stage_done[b], ctx->stream);
+            if (e != hipSuccess) return fail(MSQ_ERR_HIP, "hipEventRecord", e);
+        }
+        r0 = r1;
+    }
+    uint64_t res[2] = {~0ull, 0};
+    {
+        hipError_t e = hipMemcpyAsync(res, scratch, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(MSQ_ERR_HIP, "result copy", e);
+    }
+    (void)hipFree(d_base_off);
+    d_base_off = nullptr;
+    if (res[0] != ~0ull) {
+        free_packed_dev(d);
+        // std::runtime_error("Unexpected cigar " + std::to_string(b.Cigar)), src/MSA.cpp:182
+        return msq_fail(MSQ_ERR_CIGAR, "Unexpected cigar %d", (int)(res[0] & 0xff));
+    }
+    msq_packed_reads& v = d->view;
+    v.n_reads = n_reads;
+    v.n_groups = n_groups;
+    v.ref_start = (const int32_t*)d->ptrs[0];
+    v.ref_end = (const int32_t*)d->ptrs[1];
+    v.group_off = (const uint64_t*)d->ptrs[2];
+    v.bop = (const uint32_t*)d->ptrs[3];
+    v.qual = (const uint8_t*)d->ptrs[4];
+    v.delqv = (const uint8_t*)d->ptrs[5];
+    v.subqv = (const uint8_t*)d->ptrs[6];
+    v.insqv = (const uint8_t*)d->ptrs[7];
+    v.flags = ((uint32_t)res[1] & MSQ_READS_HAS_EXOTIC) | MSQ_READS_NORMALIZED;
+    v.reserved = 0;
+    *out = d;
     return MSQ_OK;
 }

@@ -80,6 +80,50 @@ def pack_host(reads):
     return out
 
 
+def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases=0):
+    """msq_pack_reads_device on unpacked reads (the dict pack_host takes) -> the packed arrays copied back from HBM,
+    in pack_host()'s layout.  has_qual / has_rich: per-base presence bytes (default: present wherever the dict
+    holds the QV array)."""
+    L = abi.lib()
+    n = int(reads["n_reads"])
+    off = np.asarray(reads["base_off"], dtype=np.int64)
+    total = int(off[-1]) if n else 0
+    rec = np.zeros((max(total, 1), 8), dtype=np.uint8)  # msq_array_base records
+    rec[:total, 0] = reads["cigar"][:total]
+    rec[:total, 1] = reads["nuc"][:total]
+    if reads.get("qual") is not None:
+        rec[:total, 2] = 1 if has_qual is None else has_qual
+        rec[:total, 4] = reads["qual"][:total]
+    if reads.get("subqv") is not None:
+        rec[:total, 3] = 1 if has_rich is None else has_rich
+        rec[:total, 5] = reads["delqv"][:total]
+        rec[:total, 6] = reads["subqv"][:total]
+        rec[:total, 7] = reads["insqv"][:total]
+    ptrs = (rec.ctypes.data + off[:-1] * 8).astype(np.uint64)
+    lens = np.diff(off).astype(np.int64)
+    h = C.c_void_p()
+    abi.check(L.msq_pack_reads_device(ctx.h, n, abi.ptr(reads["ref_start"]), abi.ptr(reads["ref_end"]), abi.ptr(ptrs), abi.ptr(lens),
+                                      threads, chunk_bases, C.byref(h)))
+    try:
+        v = L.msq_packed_dev_view(h).contents
+        g = int(v.n_groups)
+
+        def back(addr, dtype, count):
+            if not addr:
+                return None
+            a = np.zeros(count, dtype=dtype)
+            if count:
+                abi.check(L.msq_memcpy_d2h(ctx.h, abi.ptr(a), addr, a.nbytes))
+            return a
+        out = {"n_reads": int(v.n_reads), "n_groups": g, "ref_start": back(v.ref_start, np.int32, n), "ref_end": back(v.ref_end, np.int32, n),
+               "group_off": back(v.group_off, np.uint64, n + 1), "bop": back(v.bop, np.uint32, g * 4),
+               "qual": back(v.qual, np.uint8, g * 32), "delqv": back(v.delqv, np.uint8, g * 32),
+               "subqv": back(v.subqv, np.uint8, g * 32), "insqv": back(v.insqv, np.uint8, g * 32), "flags": int(v.flags)}
+    finally:
+        L.msq_packed_dev_free(ctx.h, h)
+    return out
+
+
 class DeviceReads:
     """Packed reads resident in HBM (torch tensors own the memory) + the msq_packed_reads view of them."""
 

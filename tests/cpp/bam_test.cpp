@@ -13,17 +13,37 @@
 int main(int argc, char** argv)
 {
     if (argc < 4) {
-        std::fprintf(stderr, "usage: bam_test file.bam regionStart regionEnd [--call] [--threads N]\n");
+        std::fprintf(stderr, "usage: bam_test file.bam regionStart regionEnd [--call] [--time] [--threads N]\n");
         return 2;
     }
-    bool call = false;
+    bool call = false, time_only = false;
     unsigned threads = 4;
     for (int i = 4; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--call")) call = true;
+        if (!std::strcmp(argv[i], "--time")) time_only = true;
         if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)std::atoi(argv[++i]);
     }
     try {
-        const auto reads = IO::BamUtils::BamToArrayReads(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), threads);
+        IO::BamTimings tm;
+        const auto reads = IO::BamUtils::BamToArrayReads(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), threads, &tm);
+        if (time_only) {  // decode rate of the front on its own (host only)
+            size_t bases = 0;
+            for (const auto& r : reads) bases += r->Bases().size();
+            double call_s = 0, call2_s = 0;
+            if (call) {  // + ArrayReads -> packed upload -> pileup -> Fisher (AminoAcidCaller's constructor), twice
+                const Juliet::ErrorEstimates error("S/P2-C2");
+                Juliet::JulietSettings s;
+                for (int rep = 0; rep < 2; ++rep) {
+                    const auto c0 = std::chrono::steady_clock::now();
+                    Juliet::AminoAcidCaller aac(reads, error, s);
+                    (rep ? call2_s : call_s) = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+                }
+            }
+            std::printf("TIMING threads %u file_bytes %zu bam_bytes %zu records %zu kept %zu bases %zu read_s %.4f inflate_s %.4f index_s %.4f parse_s %.4f "
+                        "call_first_s %.4f call_s %.4f\n",
+                        threads, tm.file_bytes, tm.bam_bytes, tm.records, tm.kept, bases, tm.read, tm.inflate, tm.index, tm.parse, call_s, call2_s);
+            return 0;
+        }
         std::printf("READS bam\n");
         for (const auto& r : reads) {
             const auto& bases = r->Bases();
@@ -39,7 +59,7 @@ int main(int argc, char** argv)
                     std::printf("%s%d", i ? "," : "", k == 0 ? x.QualQV : k == 1 ? x.SubQV : k == 2 ? x.DelQV : x.InsQV);
                 }
             }
-            std::printf(" NAME %s\n", r->Name().c_str());
+            std::printf(" NAME %s CHEM %s\n", r->Name().c_str(), r->SequencingChemistry().empty() ? "." : r->SequencingChemistry().c_str());
         }
         if (call) {
             const Juliet::ErrorEstimates error("S/P2-C2");

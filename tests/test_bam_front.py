@@ -61,8 +61,13 @@ def encode_record(rec):
     return struct.pack("<I", len(body)) + body
 
 
+RG_LINES = ("@RG\tID:abcd1234\tPL:PACBIO\tDS:READTYPE=CCS;BINDINGKIT=100-862-200;SEQUENCINGKIT=100-861-800;BASECALLERVERSION=5.0.0;"
+            "FRAMERATEHZ=80.000000\tPU:movie\n@RG\tID:ffff0000\tPL:PACBIO\tDS:READTYPE=CCS\tPU:other\n")
+CHEM = {"abcd1234": "100-862-200/100-861-800/5.0.0", "ffff0000": "."}
+
+
 def write_bam(path, records, ref_len, block=7000):
-    text = b"@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:ref\tLN:%d\n" % ref_len
+    text = b"@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:ref\tLN:%d\n" % ref_len + RG_LINES.encode()
     raw = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", 1) + struct.pack("<I", 4) + b"ref\0" + struct.pack("<I", ref_len)
     raw += b"".join(encode_record(r) for r in records)
     with open(path, "wb") as f:
@@ -122,7 +127,8 @@ def make_records(rng, ref, n, clean=False, rich=False):
         if rich and (clean or rng.random() < 0.8):
             for t in ("dq", "iq", "sq"):
                 tags[t] = ("Z", "".join(chr(33 + int(x)) for x in rng.integers(0, 94, len(seq))))
-        tags["RG"] = ("Z", "abcd1234")
+        if clean or rng.random() < 0.9:
+            tags["RG"] = ("Z", "abcd1234" if clean or rng.random() < 0.8 else "ffff0000")
         recs.append({"name": "movie/%d/ccs" % r, "flag": flag, "pos": a, "cigar": [tuple(x) for x in cigar], "seq": seq, "qual": qual,
                      "tags": tags})
     return recs
@@ -164,7 +170,8 @@ def expected_reads(records, region_start, region_end):
                     qs[k].append(lane[qp] if qry_c else 0)
             rp += ref_c
             qp += qry_c
-        out.append((c_lo, c_hi, "".join(cig), "".join(nuc), qs, rec["name"]))
+        chem = CHEM[rec["tags"]["RG"][1]] if "RG" in rec["tags"] else "."
+        out.append((c_lo, c_hi, "".join(cig), "".join(nuc), qs, rec["name"], chem))
     return out
 
 
@@ -176,7 +183,7 @@ def run_bam_test(path, region_start, region_end, *extra):
         t = line.split(" ")
         if t[0] == "READ":
             k = t.index("NAME")
-            reads.append((int(t[1]), int(t[2]), t[3], t[4], [[int(x) for x in f.split(",")] if f else [] for f in t[5:k]], t[k + 1]))
+            reads.append((int(t[1]), int(t[2]), t[3], t[4], [[int(x) for x in f.split(",")] if f else [] for f in t[5:k]], t[k + 1], t[k + 3]))
         else:
             rest.append(line)
     return out.returncode, reads, rest

@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Decode rate of the BAM front (minorseq_amd/cpp/msq_bam.hpp) on its own: writes a synthetic BAM of `--reads`
+full-length CCS-like records over a `--columns` window (=/X/I/D cigars, QUAL, optional sq/dq/iq tags), then times
+tests/cpp/bam_test --time for several thread counts.  Host only; prints one JSON line per thread count.
+
+  python tools/bench_bam.py [--reads 20000] [--columns 2843] [--rich] [--threads 1,4,8,16] [--out file.json]
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "bam_test")
+SEQ_CODE = np.zeros(256, dtype=np.uint8)
+for _i, _c in enumerate("=ACMGRSVTWYHKDBN"):
+    SEQ_CODE[ord(_c)] = _i
+
+
+def bgzf_block(payload):
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+    comp = co.compress(payload) + co.flush()
+    return (struct.pack("<BBBBIBBH", 31, 139, 8, 4, 0, 0, 255, 6) + b"BC" + struct.pack("<HH", 2, 18 + len(comp) + 8 - 1) + comp
+            + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+
+
+def record(rng, ref_codes, r, rich):
+    W = len(ref_codes)
+    u = rng.random(W)
+    op = np.where(u < 0.004, 2, np.where(u < 0.006, 8, 7)).astype(np.uint8)  # D / X / =
+    op[0] = op[-1] = 7
+    ins = np.flatnonzero(rng.random(W) < 0.004)
+    ops = np.insert(op, ins, 1)  # I before the column
+    change = np.flatnonzero(np.diff(ops)) + 1
+    starts = np.concatenate(([0], change))
+    lens = np.diff(np.concatenate((starts, [len(ops)])))
+    cigar = ((lens.astype(np.uint32) << 4) | ops[starts]).astype("<u4").tobytes()
+    base = np.insert(ref_codes, ins, rng.integers(0, 4, len(ins)).astype(np.uint8))
+    sub = ops == 8
+    base[sub] = (base[sub] + 1) & 3
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[base[ops != 2]]
+    n = len(seq)
+    codes = SEQ_CODE[seq]
+    if n & 1:
+        codes = np.append(codes, 0)
+    packed = ((codes[0::2] << 4) | codes[1::2]).astype(np.uint8).tobytes()
+    qual = rng.integers(20, 94, n).astype(np.uint8).tobytes()
+    name = b"m54000_170101_000000/%d/ccs\0" % r
+    tags = b"RGZabcd1234\0" + b"npi" + struct.pack("<i", 12) + b"rqf" + struct.pack("<f", 0.999)
+    if rich:
+        for t in (b"dq", b"iq", b"sq"):
+            tags += t + b"Z" + (rng.integers(33, 127, n).astype(np.uint8)).tobytes() + b"\0"
+    body = struct.pack("<iiBBHHHIiii", 0, 0, len(name), 255, 4680, len(lens), 16 if r & 1 else 0, n, -1, -1, 0)
+    body += name + cigar + packed + qual + tags
+    return struct.pack("<I", len(body)) + body
+
+
+def write(path, n_reads, W, rich):
+    rng = np.random.default_rng(1)
+    ref_codes = rng.integers(0, 4, W).astype(np.uint8)
+    text = (b"@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:ref\tLN:%d\n@RG\tID:abcd1234\tPL:PACBIO\tDS:READTYPE=CCS;BINDINGKIT=1;"
+            b"SEQUENCINGKIT=2;BASECALLERVERSION=5.0\n" % W)
+    buf = bytearray(b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<II", 1, 4) + b"ref\0" + struct.pack("<I", W))
+    with open(path, "wb") as f:
+        for r in range(n_reads):
+            buf += record(rng, ref_codes, r, rich)
+            while len(buf) >= 65280:  # htslib's block payload
+                f.write(bgzf_block(bytes(buf[:65280])))
+                del buf[:65280]
+        if buf:
+            f.write(bgzf_block(bytes(buf)))
+        f.write(bgzf_block(b""))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=20000)
+    ap.add_argument("--columns", type=int, default=2843)
+    ap.add_argument("--rich", action="store_true")
+    ap.add_argument("--threads", default="1,4,8,16")
+    ap.add_argument("--call", action="store_true", help="also time AminoAcidCaller on the decoded reads (needs the GPU)")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    assert os.path.exists(BIN), "tests/cpp/bam_test not built: run __graft_entry__.build()"
+    lines = []
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "bench.bam")
+        write(path, a.reads, a.columns, a.rich)
+        for t in [int(x) for x in a.threads.split(",")]:
+            best = None
+            for _ in range(3):
+                out = subprocess.run([BIN, path, "0", "2147483647", "--time", "--threads", str(t)] + (["--call"] if a.call else []), capture_output=True, text=True, check=True)
+                tok = out.stdout.split()
+                kv = {tok[i]: float(tok[i + 1]) for i in range(1, len(tok) - 1, 2)}
+                total = kv["read_s"] + kv["inflate_s"] + kv["index_s"] + kv["parse_s"]
+                if best is None or total < best[0]:
+                    best = (total, kv)
+            total, kv = best
+            line = {"what": "BAM -> ArrayReads (host)", "threads": t, "reads": int(kv["kept"]), "columns": a.columns, "rich_qvs": a.rich,
+                    "reads_per_s": kv["kept"] / total, "bam_MB_per_s": kv["bam_bytes"] / total / 1e6, "seconds": total,
+                    "read_s": kv["read_s"], "inflate_s": kv["inflate_s"], "index_s": kv["index_s"], "parse_s": kv["parse_s"],
+                    "file_MB": kv["file_bytes"] / 1e6, "bam_MB": kv["bam_bytes"] / 1e6}
+            if a.call:  # BAM file -> called variants, host packing and upload included
+                line["caller_s"] = kv["call_s"]
+                line["caller_first_s"] = kv["call_first_s"]
+                line["end_to_end_reads_per_s"] = kv["kept"] / (total + kv["call_s"])
+            print(json.dumps(line), flush=True)
+            lines.append(line)
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(lines, f, indent=1)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
