@@ -19,6 +19,10 @@
 // Inflating BGZF blocks is spread over hardware threads (blocks are independent); link with -lz.
 #pragma once
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -48,20 +52,62 @@ struct BgzfBlock
     size_t out_off, out_len;  // where it inflates to (ISIZE)
 };
 
-inline std::vector<uint8_t> ReadFile(const std::string& path)
+// The file image: mapped, not copied (the inflate threads read it straight from the page cache).
+class MappedFile
 {
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) throw std::runtime_error("cannot open " + path);
-    std::vector<uint8_t> data;
-    uint8_t buf[1 << 16];
-    size_t n;
-    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) data.insert(data.end(), buf, buf + n);
-    std::fclose(f);
-    return data;
-}
+public:
+    explicit MappedFile(const std::string& path)
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("cannot open " + path);
+        struct stat st;
+        if (::fstat(fd, &st) != 0) {
+            ::close(fd);
+            throw std::runtime_error("cannot stat " + path);
+        }
+        n_ = (size_t)st.st_size;
+        if (n_) {
+            void* m = ::mmap(nullptr, n_, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) {
+                ::close(fd);
+                throw std::runtime_error("cannot map " + path);
+            }
+            p_ = static_cast<const uint8_t*>(m);
+        }
+        ::close(fd);
+    }
+    MappedFile(const MappedFile&) = delete;
+    MappedFile& operator=(const MappedFile&) = delete;
+    ~MappedFile()
+    {
+        if (p_) ::munmap(const_cast<uint8_t*>(p_), n_);
+    }
+    size_t size() const { return n_; }
+    const uint8_t& operator[](size_t i) const { return p_[i]; }
+
+private:
+    const uint8_t* p_ = nullptr;
+    size_t n_ = 0;
+};
+
+// The inflated BAM stream: allocated without zero-filling (every byte is written by an inflate thread).
+class Bytes
+{
+public:
+    explicit Bytes(size_t n) : p_(new uint8_t[n ? n : 1]), n_(n) {}
+    size_t size() const { return n_; }
+    uint8_t* data() { return p_.get(); }
+    const uint8_t* data() const { return p_.get(); }
+    uint8_t& operator[](size_t i) { return p_[i]; }
+    const uint8_t& operator[](size_t i) const { return p_[i]; }
+
+private:
+    std::unique_ptr<uint8_t[]> p_;
+    size_t n_;
+};
 
 // BGZF (SAMv1 4.1): gzip members with FEXTRA holding the subfield 'B','C',2,BSIZE; inflate them in parallel.
-inline std::vector<uint8_t> InflateBgzf(const std::vector<uint8_t>& file, unsigned threads)
+inline Bytes InflateBgzf(const MappedFile& file, unsigned threads)
 {
     std::vector<BgzfBlock> blocks;
     size_t off = 0, out = 0;
@@ -82,7 +128,7 @@ inline std::vector<uint8_t> InflateBgzf(const std::vector<uint8_t>& file, unsign
         out += isize;
         off += bsize;
     }
-    std::vector<uint8_t> data(out);
+    Bytes data(out);
     auto work = [&](size_t first, size_t step) {
         for (size_t b = first; b < blocks.size(); b += step) {
             const BgzfBlock& k = blocks[b];
@@ -201,11 +247,10 @@ struct BamUtils
         regionStart = std::max(regionStart - 1, 0);
         regionEnd = std::max(regionEnd - 1, 0);
         const auto t0 = Clock::now();
-        std::vector<uint8_t> file = ReadFile(filePath);
+        const MappedFile file(filePath);
         const auto t1 = Clock::now();
-        const std::vector<uint8_t> data = InflateBgzf(file, threads);
+        const Bytes data = InflateBgzf(file, threads);
         const size_t file_bytes = file.size();
-        std::vector<uint8_t>().swap(file);
         const auto t2 = Clock::now();
         if (data.size() < 12 || std::memcmp(data.data(), "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file: " + filePath);
         size_t off = 4;
@@ -392,17 +437,24 @@ private:
                 if (cons_query) qp += len;
                 continue;
             }
-            for (size_t i = 0; i < len; ++i) {
-                const bool inside = cons_ref ? (rp >= clip_lo && rp < clip_hi) : (rp >= clip_lo && rp <= clip_hi);
-                if (inside) {
-                    if (cons_query)
-                        emit(kOps[op], kSeq[(seq[qp >> 1] >> ((qp & 1) ? 0 : 4)) & 15], true, qp);
-                    else
-                        emit(kOps[op], op == 6 ? '*' : '-', false, 0);
-                }
-                if (cons_ref) ++rp;
-                if (cons_query) ++qp;
+            // the part of this run that lies inside the clip interval (a run that consumes no reference sits at rp)
+            size_t skip = 0, count = len;
+            if (cons_ref) {
+                const int64_t first = std::max<int64_t>(rp, clip_lo), last = std::min<int64_t>(rp + (int64_t)len, clip_hi);
+                skip = (size_t)std::max<int64_t>(first - rp, 0);
+                count = last > first ? (size_t)(last - first) : 0;
+            } else if (!(rp >= clip_lo && rp <= clip_hi)) {
+                count = 0;
             }
+            if (cons_query) {
+                const char opc = kOps[op];
+                for (size_t q = qp + skip, e = qp + skip + count; q < e; ++q) emit(opc, kSeq[(seq[q >> 1] >> ((q & 1) ? 0 : 4)) & 15], true, q);
+                qp += len;
+            } else {
+                const char opc = kOps[op], nt = op == 6 ? '*' : '-';
+                for (size_t i = 0; i < count; ++i) emit(opc, nt, false, 0);
+            }
+            if (cons_ref) rp += (int64_t)len;
         }
         return std::make_shared<BAMArrayRead>(idx, std::string(reinterpret_cast<const char*>(name)), (size_t)clip_lo, (size_t)clip_hi,
                                               std::move(bases), std::move(chemistry));

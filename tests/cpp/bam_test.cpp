@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <malloc.h>
 
 #include "../../minorseq_amd/cpp/msq_bam.hpp"
 #include "dump.hpp"
@@ -21,6 +22,7 @@ int main(int argc, char** argv)
     for (int i = 4; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--call")) call = true;
         if (!std::strcmp(argv[i], "--time")) time_only = true;
+        if (!std::strcmp(argv[i], "--top-pad") && i + 1 < argc) mallopt(M_TOP_PAD, std::atoi(argv[++i]) << 20);  // experiment: arena growth step, MB
         if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)std::atoi(argv[++i]);
     }
     try {

@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--rich", action="store_true")
     ap.add_argument("--threads", default="1,4,8,16")
     ap.add_argument("--call", action="store_true", help="also time AminoAcidCaller on the decoded reads (needs the GPU)")
+    ap.add_argument("--extra", default="", help="extra arguments for bam_test (experiments)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     assert os.path.exists(BIN), "tests/cpp/bam_test not built: run __graft_entry__.build()"
@@ -95,7 +96,7 @@ def main():
         for t in [int(x) for x in a.threads.split(",")]:
             best = None
             for _ in range(3):
-                out = subprocess.run([BIN, path, "0", "2147483647", "--time", "--threads", str(t)] + (["--call"] if a.call else []), capture_output=True, text=True, check=True)
+                out = subprocess.run([BIN, path, "0", "2147483647", "--time", "--threads", str(t)] + (["--call"] if a.call else []) + a.extra.split(), capture_output=True, text=True, check=True)
                 tok = out.stdout.split()
                 kv = {tok[i]: float(tok[i + 1]) for i in range(1, len(tok) - 1, 2)}
                 total = kv["read_s"] + kv["inflate_s"] + kv["index_s"] + kv["parse_s"]
