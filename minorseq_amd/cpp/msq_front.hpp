@@ -32,12 +32,14 @@
 #include <map>
 #include <memory>
 #include <numeric>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/msq_abi.h"
+#include "msq_json.hpp"
 
 namespace PacBio {
 namespace Msq {
@@ -469,6 +471,16 @@ struct PerformanceMetrics  // include/pacbio/juliet/AminoAcidCaller.h:55-78
     double TruePositiveRate() const { return TruePositives / NumExpectedMinors; }
     double FalsePositiveRate() const { return FalsePositives / (NumberOfTests - NumExpectedMinors); }
     double Accuracy() const { return (TruePositives + TrueNegative) / (TruePositives + FalsePositives + FalseNegative + TrueNegative); }
+    std::string ToJson() const  // src/AminoAcidCaller.cpp:579-588 (ostream formatting of doubles: 6 significant digits)
+    {
+        std::stringstream ss;
+        ss << "{\"true_positive_rate\":" << TruePositiveRate() << ",";
+        ss << "\"false_positive_rate\":" << FalsePositiveRate() << ",";
+        ss << "\"num_tests\":" << NumberOfTests << ",";
+        ss << "\"num_false_positives\":" << FalsePositives << ",";
+        ss << "\"accuracy\":" << Accuracy() << "}";
+        return ss.str();
+    }
 };
 
 struct VariantGene  // include/pacbio/juliet/VariantGene.h:49-81
@@ -506,6 +518,60 @@ struct VariantGene  // include/pacbio/juliet/VariantGene.h:49-81
         }
     };
     std::map<int, std::shared_ptr<VariantPosition>> relPositionToVariant;
+
+    JSON::Json ToJson() const  // src/VariantGene.cpp:42-81
+    {
+        using JSON::Json;
+        Json root;
+        root["name"] = geneName;
+        std::vector<Json> positions;
+        for (const auto& pos_variant : relPositionToVariant) {
+            const VariantPosition& vp = *pos_variant.second;
+            if (vp.aminoAcidToCodons.empty()) continue;
+            Json jVarPos;
+            jVarPos["ref_position"] = pos_variant.first;
+            jVarPos["ref_codon"] = vp.refCodon;
+            jVarPos["coverage"] = vp.coverage;
+            jVarPos["ref_amino_acid"] = std::string(1, vp.refAminoAcid);
+            std::vector<Json> jVarAAs;
+            for (const auto& aa_varCodon : vp.aminoAcidToCodons) {
+                if (aa_varCodon.second.empty()) continue;
+                Json jVarAA;
+                jVarAA["amino_acid"] = std::string(1, aa_varCodon.first);
+                std::vector<Json> jCodons;
+                for (const auto& codon : aa_varCodon.second) {
+                    Json jCodon;
+                    jCodon["codon"] = codon.codon;
+                    jCodon["frequency"] = codon.frequency;
+                    jCodon["pValue"] = codon.pValue;
+                    jCodon["known_drm"] = codon.knownDRM;
+                    jCodon["haplotype_hit"] = codon.haplotypeHit;
+                    jCodons.push_back(jCodon);
+                }
+                jVarAA["variant_codons"] = jCodons;
+                jVarAAs.push_back(jVarAA);
+            }
+            jVarPos["variant_amino_acids"] = jVarAAs;
+            std::vector<Json> jMsa;  // the objects of src/AminoAcidCaller.cpp:549-563
+            for (const auto& m : vp.msa) {
+                Json msaCounts;
+                msaCounts["rel_pos"] = m.rel_pos;
+                msaCounts["abs_pos"] = m.abs_pos;
+                msaCounts["A"] = m.A;
+                msaCounts["C"] = m.C;
+                msaCounts["G"] = m.G;
+                msaCounts["T"] = m.T;
+                msaCounts["-"] = m.gap;
+                msaCounts["N"] = m.N;
+                msaCounts["wt"] = m.wt;
+                jMsa.push_back(msaCounts);
+            }
+            jVarPos["msa"] = jMsa;
+            positions.push_back(jVarPos);
+        }
+        if (!positions.empty()) root["variant_positions"] = positions;
+        return root;
+    }
 };
 
 enum class HaplotypeType : int  // include/pacbio/juliet/Haplotype.h:46-54
@@ -518,7 +584,7 @@ enum class HaplotypeType : int  // include/pacbio/juliet/Haplotype.h:46-54
     OFFTARGET = 16
 };
 
-class Haplotype  // include/pacbio/juliet/Haplotype.h:56-126, internal/Haplotype.inl, src/Haplotype.cpp (ToJson: not mirrored)
+class Haplotype  // include/pacbio/juliet/Haplotype.h:56-126, internal/Haplotype.inl, src/Haplotype.cpp
 {
 public:
     Haplotype() = delete;
@@ -549,6 +615,17 @@ public:
     void AddReadName(const std::string& name) { readNames_.push_back(name); }
     void AddSoftReadCount(const double s) { softCollapses_ += s; }
     void Name(const std::string& name) { name_ = name; }
+    JSON::Json ToJson() const  // src/Haplotype.cpp:59-70
+    {
+        JSON::Json root;
+        root["name"] = name_;
+        root["reads_hard"] = readNames_.size();
+        root["reads_soft"] = Size();
+        root["frequency"] = frequency_;
+        root["read_names"] = readNames_;
+        root["codons"] = codons_;
+        return root;
+    }
 
 private:
     std::string name_;
@@ -665,6 +742,30 @@ public:
             if (kv.first == static_cast<int>(HaplotypeType::LOW_COV)) lowCov_ += kv.second;
             if (kv.first & static_cast<int>(HaplotypeType::OFFTARGET)) margOfftarget_ += kv.second;
         }
+    }
+    /// The report juliet writes with dump(2) (src/AminoAcidCaller.cpp:590-619).
+    JSON::Json JSON() const
+    {
+        using JSON::Json;
+        Json root;
+        std::vector<Json> genes;
+        for (const auto& v : variantGenes_) {
+            Json j = v.ToJson();
+            if (j.find("variant_positions") != j.cend()) genes.push_back(j);
+        }
+        root["genes"] = genes;
+        std::vector<Json> haplotypes;
+        for (const auto& h : reconstructedHaplotypes_) haplotypes.push_back(h.ToJson());
+        root["haplotypes"] = haplotypes;
+        Json counts;
+        counts["healthy_reported"] = genCounts_;
+        counts["healthy_low_coverage"] = lowCov_;
+        counts["all_damaged"] = margOfftarget_;
+        counts["marginal_with_gaps"] = margWithGap_;
+        counts["marginal_with_heteroduplexes"] = margWithHetero_;
+        counts["marginal_partial_reads"] = margPartial_;
+        root["haplotype_read_counts"] = counts;
+        return root;
     }
     const std::vector<Haplotype>& ReconstructedHaplotypes() const { return reconstructedHaplotypes_; }
     const std::vector<Haplotype>& FilteredHaplotypes() const { return filteredHaplotypes_; }
@@ -838,6 +939,44 @@ private:
     std::unique_ptr<PerformanceMetrics> pm_;
     std::vector<Haplotype> reconstructedHaplotypes_, filteredHaplotypes_;  // AminoAcidCaller.h:138-139
     int genCounts_ = 0, margWithGap_ = 0, margWithHetero_ = 0, margPartial_ = 0, lowCov_ = 0, margOfftarget_ = 0;  // :148-153
+};
+
+/// The statements of src/tools/JulietWorkflow.cpp that only format what the path computed (the CLI, the HTML
+/// report and the file handling around them stay with the caller).
+struct JulietWorkflow
+{
+    /// `jsonStream << json.dump(2) << std::endl;` (JulietWorkflow.cpp:165-170)
+    static void WriteJson(std::ostream& jsonStream, const AminoAcidCaller& aac) { jsonStream << aac.JSON().dump(2) << std::endl; }
+    /// the --msa table: "pos A C G T - N", then one line per column with its 1-based position (JulietWorkflow.cpp:178-191)
+    static void WriteMsa(std::ostream& msaStream, const Data::MSAByColumn& msa)
+    {
+        msaStream << "pos A C G T - N" << std::endl;
+        int pos = msa.BeginPos();
+        for (const auto& column : msa) {
+            ++pos;
+            msaStream << pos;
+            for (const auto& c : {'A', 'C', 'G', 'T', '-', 'N'}) msaStream << " " << column[c];
+            msaStream << std::endl;
+        }
+    }
+    /// --mode-error (JulietWorkflow.cpp:193-213): mean deletion and substitution frequency over the columns with
+    /// coverage > 100; prints "<file>\nsub: <x>\ndel: <y>\n" as the reference does (0/0 = nan without such a column).
+    static void Error(std::ostream& out, const std::string& inputFile, const Data::MSAByColumn& msa)
+    {
+        double sub = 0;
+        double del = 0;
+        int columnCount = 0;
+        for (const auto& column : msa) {
+            if (column.Coverage() > 100) {
+                del += column.Frequency('-');
+                sub += 1.0 - column.Frequency('-') - column.Frequency(column.MaxBase());
+                ++columnCount;
+            }
+        }
+        out << inputFile << std::endl;
+        out << "sub: " << (sub / columnCount) << std::endl;
+        out << "del: " << (del / columnCount) << std::endl;
+    }
 };
 }  // namespace Juliet
 }  // namespace PacBio

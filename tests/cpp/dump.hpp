@@ -2,6 +2,7 @@
 // (parsed by tests/test_gpu_cpp_front.py).
 #pragma once
 #include <cstdio>
+#include <sstream>
 #include <string>
 
 #include "../../minorseq_amd/cpp/msq_front.hpp"
@@ -44,4 +45,23 @@ static void Dump(const char* name, Juliet::AminoAcidCaller& aac)
         }
     const auto& pm = aac.Performance();
     std::printf("PERF %g %g %g %g\n", pm.TruePositives, pm.FalsePositives, pm.FalseNegative, pm.TrueNegative);
+}
+
+// The report (AminoAcidCaller::JSON().dump(2), src/tools/JulietWorkflow.cpp:165-170), the --msa table (:178-191) and
+// the --mode-error lines (:193-213), each between marker lines.
+[[maybe_unused]] static void DumpReports(const char* name, const Juliet::AminoAcidCaller& aac)
+{
+    std::printf("JSON %s\n", name);
+    std::ostringstream js;
+    Juliet::JulietWorkflow::WriteJson(js, aac);
+    std::fputs(js.str().c_str(), stdout);
+    std::printf("ENDJSON\nMSATABLE %s\n", name);
+    std::ostringstream ms;
+    Juliet::JulietWorkflow::WriteMsa(ms, aac.msaByColumn_);
+    std::fputs(ms.str().c_str(), stdout);
+    std::printf("ENDMSATABLE\nERRMODE %s\n", name);
+    std::ostringstream es;
+    Juliet::JulietWorkflow::Error(es, "input.bam", aac.msaByColumn_);
+    std::fputs(es.str().c_str(), stdout);
+    std::printf("ENDERRMODE\n");
 }

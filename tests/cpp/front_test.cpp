@@ -115,6 +115,19 @@ int main()
     // FisherTest.EquivalentWithR
     for (int i = 0; i <= 100; ++i) std::printf("FISHER %d %.17g\n", i, Statistics::Fisher::fisher_exact_tiss(i, 1000, 10, 1000));
 
+    {  // the serializer's fixed points (msq_json.hpp): empty containers, escapes, integral / small / negative doubles
+        JSON::Json j;
+        j["b"] = std::vector<JSON::Json>{};
+        j["a"] = JSON::Json();
+        j["s"] = std::string("q\"\\\n\t\x01z");
+        j["d"] = std::vector<double>{1.0, 0.1, -2.5e-7, 1e21, 0.0, 123456789.125};
+        j["n"]["deep"] = std::vector<bool>{true, false};
+        j["u"] = size_t(18446744073709551615ull);
+        j["i"] = -7;
+        std::printf("JSONFORM %s\n", j.dump().c_str());
+        std::printf("JSON form\n%s\nENDJSON\n", j.dump(2).c_str());
+    }
+
     std::string ref;
     for (int i = 0; i < 180; ++i) ref += "ACGT"[rnd() % 4];
     const int start0 = 40;
@@ -131,6 +144,7 @@ int main()
         Juliet::AminoAcidCaller aac(reads, error, s);
         Dump("noconfig", aac);
         DumpPhase("noconfig", aac);
+        DumpReports("noconfig", aac);
 
         Juliet::JulietSettings c;  // two genes in different frames + reference + DRMs + expected minors
         Juliet::DRM drm1{"drugA", {Juliet::DMutation('*', 11, '*')}};
@@ -141,6 +155,7 @@ int main()
         Juliet::AminoAcidCaller aac2(reads, error, c);
         Dump("config", aac2);
         DumpPhase("config", aac2);
+        DumpReports("config", aac2);
         c.DRMOnly = true;
         Juliet::AminoAcidCaller aac3(reads, error, c);
         Dump("drmonly", aac3);
@@ -157,6 +172,7 @@ int main()
         Juliet::AminoAcidCaller aac(reads, error, s);  // SUBQV defaults to 42 (src/QvThresholds.cpp:53)
         Dump("rich_default_subqv42", aac);
         DumpPhase("rich_default_subqv42", aac);
+        DumpReports("rich_default_subqv42", aac);
     }
     // exceptions keep the reference's types and texts
     try {

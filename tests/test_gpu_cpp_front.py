@@ -30,8 +30,23 @@ def dump():
     assert out.returncode == 0, out.stderr[-2000:]
     d = {"fisher": {}, "reads": {}, "cases": {}, "err": [], "ref": None, "phase": {}}
     cur_reads = cur_case = cur_phase = None
+    d["json"], d["msatable"], d["errmode"] = {}, {}, {}
+    block = None  # (kind, name, lines) while inside a JSON / MSATABLE / ERRMODE block
     for line in out.stdout.splitlines():
         t = line.split(" ")
+        if block is not None:
+            if line == "END" + block[0]:
+                d[block[0].lower()][block[1]] = "\n".join(block[2]) + "\n"
+                block = None
+            else:
+                block[2].append(line)
+            continue
+        if t[0] in ("JSON", "MSATABLE", "ERRMODE"):
+            block = (t[0], t[1], [])
+            continue
+        if t[0] == "JSONFORM":
+            d["jsonform"] = line[len("JSONFORM "):]
+            continue
         if t[0] == "PHASE":
             cur_phase = d["phase"].setdefault(t[1], {"vpos": [], "hit": [], "report": []})
         elif t[0] == "ENDPHASE":
@@ -236,3 +251,95 @@ def test_exceptions_keep_reference_types(dump):
     assert e[0] == "runtime_error Unexpected cigar 78"   # std::to_string('N'), src/MSA.cpp:182
     assert e[1] == "runtime_error Unexpected base"       # src/MSA.cpp:85
     assert e[2].startswith("out_of_range")               # referenceSequence.substr, src/AminoAcidCaller.cpp:446
+
+
+@pytest.mark.parametrize("case", ["noconfig", "config", "rich_default_subqv42"])
+def test_json_report(dump, case):
+    """AminoAcidCaller::JSON().dump(2) (src/AminoAcidCaller.cpp:590-619, src/VariantGene.cpp:42-81,
+    src/Haplotype.cpp:59-70).  Content: exactly the stored variants, 9-column contexts, haplotypes and
+    read counts the tests above compared with the oracle.  Form: nlohmann's dump(2) -- sorted keys, two spaces,
+    one member per line -- which is also Python's json.dumps(indent=2, sort_keys=True); numbers are compared as
+    values ("%.15g" here, see msq_json.hpp; parity unpinned, the reference holds no JSON fixture)."""
+    import re
+    text = dump["json"][case]
+    rep = json.loads(text)
+    c, ph = dump["cases"][case], dump["phase"][case]
+    assert sorted(rep) == ["genes", "haplotype_read_counts", "haplotypes"]
+    num = re.compile(r"-?\d+\.\d+(?:e[+-]?\d+)?|-?\d+e[+-]?\d+")
+    relaid = json.dumps(rep, indent=2, sort_keys=True, ensure_ascii=False) + "\n"
+    assert num.sub("#", text) == num.sub("#", relaid)
+    for a, b in zip(num.findall(text), num.findall(relaid)):
+        assert abs(float(a) - float(b)) <= 1e-14 * abs(float(b))
+    close = lambda x, y: abs(x - y) <= 1e-14 * abs(y) + 1e-300
+
+    hits = {(g, p, cod): bits for g, p, cod, bits in ph["hit"]}
+    seen_var, seen_msa = [], []
+    for gene in rep["genes"]:
+        gname = gene["name"].replace(" ", "_")
+        assert sorted(gene) == ["name", "variant_positions"]
+        for vp in gene["variant_positions"]:
+            assert sorted(vp) == ["coverage", "msa", "ref_amino_acid", "ref_codon", "ref_position", "variant_amino_acids"]
+            for aa in vp["variant_amino_acids"]:
+                for vc in aa["variant_codons"]:
+                    seen_var.append((gname, vp["ref_position"], vp["ref_codon"], aa["amino_acid"], vc["codon"], vc["frequency"],
+                                     vc["pValue"], vc["known_drm"].replace(" ", "_") or "-", vp["coverage"]))
+                    bits = hits[(gname, vp["ref_position"], vc["codon"])]
+                    assert vc["haplotype_hit"] == [b == "1" for b in bits]
+            assert vp["ref_amino_acid"] == orc.lib().orc_amino_acid(CODONS.index(vp["ref_codon"])).decode()
+            for m in vp["msa"]:
+                assert sorted(m) == ["-", "A", "C", "G", "N", "T", "abs_pos", "rel_pos", "wt"]
+                seen_msa.append((gname, vp["ref_position"], m["rel_pos"], m["abs_pos"], m["A"], m["C"], m["G"], m["T"], m["-"], m["N"],
+                                 "_" if m["wt"] == " " else m["wt"]))
+    assert len(seen_var) == len(c["var"]) > 0
+    for g, w in zip(seen_var, c["var"]):  # same order: genes, positions, amino acids, codons as stored
+        assert g[:5] == w[:5] and g[7:] == w[7:], (g, w)
+        assert close(g[5], w[5]) and close(g[6], w[6])
+    assert seen_msa == c["msa"]
+
+    rp = orc.parse_phase_report("\n".join(ph["report"]))
+    assert len(rep["haplotypes"]) == len(rp["gen"])
+    for h, w in zip(rep["haplotypes"], rp["gen"]):
+        assert sorted(h) == ["codons", "frequency", "name", "read_names", "reads_hard", "reads_soft"]
+        assert h["name"] == w["name"] and h["reads_hard"] == w["size"] and h["reads_soft"] == float(w["size"])
+        assert close(h["frequency"], w["frequency"]) and h["codons"] == w["codons"]
+        assert h["read_names"] == ["read/" + r for r in w["reads"]]
+    cnt = rep["haplotype_read_counts"]
+    assert [cnt[k] for k in ("healthy_reported", "healthy_low_coverage", "all_damaged", "marginal_with_gaps",
+                             "marginal_with_heteroduplexes", "marginal_partial_reads")] == rp["cnt"]
+
+
+def test_json_serializer_fixed_points(dump):
+    """nlohmann's published text forms that the report may not hit: null, empty containers, escapes, integral,
+    small and large doubles ("%.15g" + ".0"), 64-bit unsigned, nesting; compact and dump(2)."""
+    want = ('{"a":null,"b":[],"d":[1.0,0.1,-2.5e-07,1e+21,0.0,123456789.125],"i":-7,"n":{"deep":[true,false]},'
+            '"s":"q\\"\\\\\\n\\t\\u0001z","u":18446744073709551615}')
+    assert dump["jsonform"] == want
+    pretty = dump["json"]["form"]
+    assert json.loads(pretty) == json.loads(want)
+    assert pretty.startswith('{\n  "a": null,\n  "b": [],\n  "d": [\n    1.0,\n    0.1,\n') and pretty.endswith('\n}\n')
+    assert '  "n": {\n    "deep": [\n      true,\n      false\n    ]\n  },\n' in pretty
+
+
+@pytest.mark.parametrize("case", ["noconfig", "config", "rich_default_subqv42"])
+def test_msa_table_and_error_mode(dump, case):
+    """--msa output (src/tools/JulietWorkflow.cpp:178-191) and --mode-error (:193-213) from the count matrix."""
+    c = dump["cases"][case]
+    lines = dump["msatable"][case].splitlines()
+    assert lines[0] == "pos A C G T - N"
+    assert len(lines) == 1 + len(c["nuc"])
+    for line, x in zip(lines[1:], c["nuc"]):
+        assert [int(v) for v in line.split(" ")] == x[:7]  # RefPos (1-based) + the six counts, checked against the oracle above
+    sub = dl = n = 0.0
+    for x in c["nuc"]:
+        cov = sum(x[1:7])
+        if cov > 100:
+            gap = x[5] / cov
+            best = max(x[1:7])
+            assert x[1:7].index(best) != 5  # an 'N' majority has no Frequency(' ') in the reference either
+            dl += gap
+            sub += 1.0 - gap - best / cov
+            n += 1
+    e = dump["errmode"][case].splitlines()
+    assert e[0] == "input.bam" and e[1].startswith("sub: ") and e[2].startswith("del: ")
+    assert abs(float(e[1][5:]) - sub / n) <= 1e-5 * (sub / n)  # ostream default precision: 6 digits
+    assert abs(float(e[2][5:]) - dl / n) <= 1e-5 * (dl / n)
