@@ -95,6 +95,8 @@ typedef struct msq_packed_reads {
 
 #define MSQ_READS_HAS_EXOTIC 1u /* some base uses op 1 with nucleotide code 2 or 3 */
 #define MSQ_READS_NORMALIZED 2u /* inside every group the column-consuming bases come first (see above) */
+#define MSQ_READS_PAD_MARKED 4u /* plain layout whose padding slots carry op 3 + nucleotide code 3 ('P' / 'S' carry
+                                   code 0): the end of a read can be told from a 'P' / 'S' op (msq_insertion_*) */
 
 /* QvThresholds (include/pacbio/data/QvThresholds.h:44-54, src/QvThresholds.cpp:45-56): -1 = boost::none. */
 typedef struct msq_qv_thresholds {
@@ -135,9 +137,12 @@ typedef struct msq_array_base {
  * bit-plane packing run on the device.  The result equals msq_pack_reads + msq_reads_upload of the same bases
  * with absent QVs written as 255: same planes, NULL QV planes when no base of the set carries that QV (the QV
  * bytes of slots that hold no base are unspecified).  Unknown cigar char: MSQ_ERR_CIGAR "Unexpected cigar <code>"
- * for the first one in read order (src/MSA.cpp:182).  Synchronises. */
+ * for the first one in read order (src/MSA.cpp:182).  Synchronises.
+ * pack_flags: 0 = the normalized layout; MSQ_PACK_PLAIN = base k of a group in slot k and marked padding
+ * (MSQ_READS_PAD_MARKED), which the insertion scan needs and the pileup accepts as well. */
+#define MSQ_PACK_PLAIN 1u
 int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
-                          const msq_array_base* const* bases, const int64_t* n_bases, int threads,
+                          const msq_array_base* const* bases, const int64_t* n_bases, uint32_t pack_flags, int threads,
                           int64_t chunk_bases, msq_packed_dev** out);
 
 /* ----------------------------------------------------------------------------------------------- pileup
@@ -171,6 +176,29 @@ int msq_pileup_check(msq_ctx* ctx);
  * memory, [n_reads * n_pos].  Synchronises. */
 int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
                      int32_t W, int32_t n_pos, const int32_t* pos, uint16_t* d_keys);
+
+/* ------------------------------------------------------------------------------------- insertion histogram
+ * The insertion strings MSAByRow::AddRead records per row (`row.Insertions[pos] = insertion`, src/MSA.cpp:151-156:
+ * consecutive 'I' bases, stored at the window column of the op that follows them; a later run flushed at the same
+ * column overwrites; a run at the very end of the read is dropped) and MSAByColumn adds up per column
+ * (counts[pos].IncInsertion, src/MSA.cpp:88-90, MSA.inl:101) -- what `fuse` reads (src/tools/Fuse.cpp:99-119).
+ * d_reads must be in the plain layout with marked padding (MSQ_PACK_PLAIN).  Inserted bases are not QV-filtered;
+ * an inserted base that is not ACGT was packed as 'A'.  A run flushed at column W (the reference then writes out
+ * of bounds) is dropped. */
+typedef struct msq_insertion {
+    int32_t col;      /* window column (0-based) */
+    uint32_t len;     /* inserted bases, <= 64 */
+    uint64_t seq_lo;  /* 2 bits per base (A=0 C=1 G=2 T=3): base k at bits 2k..2k+1 of seq_lo (k < 32) */
+    uint64_t seq_hi;  /*                                     ... or bits 2(k-32).. of seq_hi */
+} msq_insertion;
+/* d_counts[col] += number of rows that record an insertion at col (any string).  Async on the stream. */
+int msq_insertion_counts(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t win_begin0, int32_t W,
+                         uint32_t* d_counts);
+/* One record per (row, column) insertion, in no particular order, for the columns whose bit is set in
+ * d_col_filter ([ceil(W/32)] words; NULL = all columns).  *n_out = records found; more than `capacity`, or an
+ * insertion longer than 64 bases: MSQ_ERR_RANGE (d_out then holds the first `capacity`).  Synchronises. */
+int msq_insertion_records(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t win_begin0, int32_t W,
+                          const uint32_t* d_col_filter, msq_insertion* d_out, uint64_t capacity, uint64_t* n_out);
 
 /* Measurement aid (no counterpart in the reference): while enabled, every msq_pileup records a HIP event pair
  * on the context's stream around its dominant kernel launch (the one that streams the packed reads), up to

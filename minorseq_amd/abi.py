@@ -15,6 +15,8 @@ MSQ_ERR_WINDOW, MSQ_ERR_RANGE, MSQ_ERR_NODEVICE, MSQ_ERR_NOMEM = -5, -6, -7, -8
 MSQ_PILEUP_AUTO, MSQ_PILEUP_SIMPLE, MSQ_PILEUP_STREAM = 0, 1, 2
 MSQ_READS_HAS_EXOTIC = 1
 MSQ_READS_NORMALIZED = 2
+MSQ_READS_PAD_MARKED = 4
+MSQ_PACK_PLAIN = 1
 
 
 class MsqError(RuntimeError):
@@ -93,7 +95,9 @@ _SIGNATURES = {
     "msq_reads_upload": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(_P)]),
     "msq_packed_dev_view": (C.POINTER(PackedReads), [_P]),
     "msq_packed_dev_free": (C.c_int, [_P, _P]),
-    "msq_pack_reads_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.c_int, C.c_int64, C.POINTER(_P)]),
+    "msq_pack_reads_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(_P)]),
+    "msq_insertion_counts": (C.c_int, [_P, C.POINTER(PackedReads), C.c_int32, C.c_int32, _P]),
+    "msq_insertion_records": (C.c_int, [_P, C.POINTER(PackedReads), C.c_int32, C.c_int32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "msq_window_bounds": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "msq_pileup": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P, C.c_int]),
     "msq_pileup_check": (C.c_int, [_P]),

@@ -274,7 +274,7 @@ private:
         msq_ctx* ctx = Msq::Context();
         msq_packed_dev* dev = nullptr;
         // "Unexpected cigar ..." -> std::runtime_error
-        Msq::Check(msq_pack_reads_device(ctx, reads.size(), rs.data(), re.data(), ptr.data(), len.data(), 0, 0, &dev));
+        Msq::Check(msq_pack_reads_device(ctx, reads.size(), rs.data(), re.data(), ptr.data(), len.data(), 0, 0, 0, &dev));
         dev_.reset(dev, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // kept for PhaseKeys
         {
             int32_t b0 = 0, e0 = 0;

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(const uint64_t* __rest
                                                           uint64_t r0, uint64_t r1, uint64_t g0, uint64_t g1, uint4* __restrict__ bop,
                                                           uint8_t* __restrict__ q_qual, uint8_t* __restrict__ q_del,
                                                           uint8_t* __restrict__ q_sub, uint8_t* __restrict__ q_ins,
-                                                          unsigned long long* __restrict__ err, uint32_t* __restrict__ flags)
+                                                          unsigned long long* __restrict__ err, uint32_t* __restrict__ flags, int plain)
 {
     __shared__ uint8_t nib[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, k = lane & 31;
@@ -234,12 +234,13 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(const uint64_t* __rest
         code = 0;
     }
     if (exotic) atomicOr(flags, MSQ_READS_HAS_EXOTIC);
-    // normalized layout: consuming bases from slot 0 up, the others from 31 down, both in genomic order
+    // normalized layout: consuming bases from slot 0 up, the others from 31 down, both in genomic order;
+    // plain layout (MSQ_PACK_PLAIN): base k in slot k, padding marked with nucleotide code 3
     const bool cons = has && op < 2, ncons = has && op >= 2;
     const uint32_t hc = (uint32_t)(__ballot(cons) >> (32 * h)), hn = (uint32_t)(__ballot(ncons) >> (32 * h));
     const uint32_t below = (1u << k) - 1u;
-    const int slot = cons ? __popc(hc & below) : 31 - __popc(hn & below);
-    nib[wave][lane] = 12;  // padding: op 3
+    const int slot = plain ? k : cons ? __popc(hc & below) : 31 - __popc(hn & below);
+    nib[wave][lane] = plain ? 15 : 12;  // padding: op 3
     __syncthreads();
     if (has) nib[wave][h * 32 + slot] = (uint8_t)(code | (op << 2));
     __syncthreads();
@@ -277,13 +278,15 @@ static void free_packed_dev(msq_packed_dev* d)
 }
 
 extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
-                                     const msq_array_base* const* bases, const int64_t* n_bases, int threads,
-                                     int64_t chunk_bases, msq_packed_dev** out)
+                                     const msq_array_base* const* bases, const int64_t* n_bases, uint32_t pack_flags,
+                                     int threads, int64_t chunk_bases, msq_packed_dev** out)
 {
     static_assert(sizeof(msq_array_base) == 8, "msq_array_base is one 8-byte record");
     if (!ctx || !out) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL argument");
     *out = nullptr;
     if (n_reads && (!ref_start || !ref_end || !bases || !n_bases)) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL array");
+    if (pack_flags & ~MSQ_PACK_PLAIN) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: unknown pack flag");
+    const int plain = (pack_flags & MSQ_PACK_PLAIN) ? 1 : 0;
     MSQ_HIP(hipSetDevice(ctx->device));
     std::vector<uint64_t> base_off, group_off;
     int64_t longest = 0;
@@ -404,10 +407,10 @@ extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32
             const uint64_t blocks = (g1 - g0 + 7) / 8;  // 4 waves x 2 groups
             hipLaunchKernelGGL(pack_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_stage, base_off[r0],
                                (const uint64_t*)d_base_off, (const uint64_t*)d->ptrs[2], r0, r1, g0, g1, (uint4*)d->ptrs[3],
-                               (uint8_t*)d->ptrs[4], (uint8_t*)d->ptrs[5], (uint8_t*)d->ptrs[6], (uint8_t*)d->ptrs[7], d_errword, d_flags);
+                               (uint8_t*)d->ptrs[4], (uint8_t*)d->ptrs[5], (uint8_t*)d->ptrs[6], (uint8_t*)d->ptrs[7], d_errword, d_flags, plain);
             e = hipGetLastError();
             if (e != hipSuccess) return fail(MSQ_ERR_HIP, "pack kernel", e);
-        } else if (chunk >= 0) {
+        } else {
             hipError_t e = hipEventRecord(ctx->stage_done[b], ctx->stream);
             if (e != hipSuccess) return fail(MSQ_ERR_HIP, "hipEventRecord", e);
         }
@@ -437,7 +440,7 @@ extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32
     v.delqv = (const uint8_t*)d->ptrs[5];
     v.subqv = (const uint8_t*)d->ptrs[6];
     v.insqv = (const uint8_t*)d->ptrs[7];
-    v.flags = ((uint32_t)res[1] & MSQ_READS_HAS_EXOTIC) | MSQ_READS_NORMALIZED;
+    v.flags = ((uint32_t)res[1] & MSQ_READS_HAS_EXOTIC) | (plain ? MSQ_READS_PAD_MARKED : MSQ_READS_NORMALIZED);
     v.reserved = 0;
     *out = d;
     return MSQ_OK;

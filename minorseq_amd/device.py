@@ -80,7 +80,7 @@ def pack_host(reads):
     return out
 
 
-def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases=0):
+def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases=0, plain=False):
     """msq_pack_reads_device on unpacked reads (the dict pack_host takes) -> the packed arrays copied back from HBM,
     in pack_host()'s layout.  has_qual / has_rich: per-base presence bytes (default: present wherever the dict
     holds the QV array)."""
@@ -103,7 +103,7 @@ def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases
     lens = np.diff(off).astype(np.int64)
     h = C.c_void_p()
     abi.check(L.msq_pack_reads_device(ctx.h, n, abi.ptr(reads["ref_start"]), abi.ptr(reads["ref_end"]), abi.ptr(ptrs), abi.ptr(lens),
-                                      threads, chunk_bases, C.byref(h)))
+                                      abi.MSQ_PACK_PLAIN if plain else 0, threads, chunk_bases, C.byref(h)))
     try:
         v = L.msq_packed_dev_view(h).contents
         g = int(v.n_groups)
@@ -224,6 +224,38 @@ def pileup(ctx, dr, thr, win_begin0, W, nuc=None, codon=None, mode=abi.MSQ_PILEU
     if check:
         abi.check(abi.lib().msq_pileup_check(ctx.h))
     return nuc, codon
+
+
+def insertion_counts(ctx, dr, win_begin0, W):
+    """msq_insertion_counts -> numpy [W]: rows recording an insertion at each window column."""
+    counts = torch.zeros(max(W, 1), dtype=torch.int32, device="cuda")
+    abi.check(abi.lib().msq_insertion_counts(ctx.h, dr.view, win_begin0, W, counts.data_ptr()))
+    return counts.cpu().numpy()[:W].astype(np.int64)
+
+
+def insertion_records(ctx, dr, win_begin0, W, cols=None, capacity=None):
+    """msq_insertion_records -> list of (col, string); cols = iterable of window columns to keep (None = all)."""
+    filt = None
+    if cols is not None:
+        bits = np.zeros((W + 31) // 32 + 1, dtype=np.uint32)
+        for c in cols:
+            bits[c >> 5] |= np.uint32(1 << (c & 31))
+        filt = torch.from_numpy(bits.view(np.int32)).cuda()
+    if capacity is None:
+        capacity = int(insertion_counts(ctx, dr, win_begin0, W).sum())
+    rec = torch.zeros(max(capacity, 1) * 3, dtype=torch.int64, device="cuda")  # msq_insertion = 24 bytes
+    n = C.c_uint64(0)
+    abi.check(abi.lib().msq_insertion_records(ctx.h, dr.view, win_begin0, W, None if filt is None else filt.data_ptr(),
+                                              rec.data_ptr(), capacity, C.byref(n)))
+    raw = rec.cpu().numpy()[:n.value * 3].reshape(-1, 3)
+    out = []
+    for head, lo, hi in raw:
+        col, ln = int(head & 0xFFFFFFFF), int((head >> 32) & 0xFFFFFFFF)
+        if col >= 1 << 31:
+            col -= 1 << 32
+        bits = (int(lo) & 0xFFFFFFFFFFFFFFFF) | ((int(hi) & 0xFFFFFFFFFFFFFFFF) << 64)
+        out.append((col, "".join("ACGT"[(bits >> (2 * k)) & 3] for k in range(ln))))
+    return out
 
 
 class Plan:

@@ -349,6 +349,60 @@ int orc_col_insertions(void* h, int col, char* buf, int buflen)
     return (int)s.size();
 }
 
+// Fuse::CreateConsensus with CollectInsertions and FindInsertions (src/tools/Fuse.cpp:70-140) on this MSA's
+// columns.  Keys are MSAColumn::RefPos() = the 1-based position (MSA.cpp:60-66).  Writes the consensus string.
+int orc_fuse(void* h, int min_coverage_recommended, char* buf, int buflen)
+{
+    Msa* m = static_cast<Msa*>(h);
+    const int actualCoverage = (int)m->rows.size();
+    int minCoverage = min_coverage_recommended;
+    if (actualCoverage < min_coverage_recommended) minCoverage = 1;  // :77-82 "permissive mode"
+    const double minInsertionCoverageFreq = 0.5;                     // Fuse.h:69
+    // CollectInsertions, :99-119: per column the most abundant in-frame insertion above half the coverage
+    std::map<int, std::pair<std::string, int>> posInsCov;
+    for (int c = 0; c < m->W; ++c) {
+        if (m->col_ins[c].empty()) continue;
+        int argmax = -1;
+        std::string max;
+        const double minInsertionCoverage = orc_col_coverage(h, c) * minInsertionCoverageFreq;
+        for (const auto& ins_count : m->col_ins[c]) {
+            if (ins_count.first.size() % 3 != 0) continue;
+            if (ins_count.second > argmax && ins_count.second > minInsertionCoverage) {
+                argmax = ins_count.second;
+                max = ins_count.first;
+            }
+        }
+        if (argmax != -1) posInsCov[m->begin0 + 1 + c] = std::make_pair(max, argmax);
+    }
+    // FindInsertions, :121-140, until the map is empty: best-covered insertion, then drop everything within 20 positions
+    std::map<int, std::string> posIns;
+    while (!posInsCov.empty()) {
+        int argMax = -1, maxCov = -1;
+        std::string ins;
+        for (const auto& kv : posInsCov)
+            if (kv.second.second > maxCov) {
+                maxCov = kv.second.second;
+                argMax = kv.first;
+                ins = kv.second.first;
+            }
+        const int windowSize = 20;
+        for (int i = std::max(0, argMax - windowSize); i < argMax + windowSize; ++i) posInsCov.erase(i);
+        posIns.insert(std::make_pair(argMax, ins));
+    }
+    std::string consensus;
+    for (int c = 0; c < m->W; ++c) {
+        const auto it = posIns.find(m->begin0 + 1 + c);
+        if (it != posIns.end()) consensus += it->second;
+        if (orc_col_coverage(h, c) >= minCoverage) {
+            const char maxBase = orc_col_maxbase(h, c);
+            if (maxBase != '-' && maxBase != ' ') consensus += maxBase;
+        }
+    }
+    if ((int)consensus.size() + 1 > buflen) return -(int)consensus.size() - 1;
+    std::memcpy(buf, consensus.c_str(), consensus.size() + 1);
+    return (int)consensus.size();
+}
+
 // Number of codon positions the caller visits: i = begin; i < end-2; (i-begin)%3==0
 // (src/AminoAcidCaller.cpp:90-94, :417-423).
 int64_t orc_count_positions(int n_genes, const int32_t* gene_begin, const int32_t* gene_end)

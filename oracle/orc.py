@@ -52,6 +52,8 @@ def lib():
         l.orc_col_maxbase.argtypes = [P, C.c_int]
         l.orc_col_insertions.restype = C.c_int
         l.orc_col_insertions.argtypes = [P, C.c_int, C.c_char_p, C.c_int]
+        l.orc_fuse.restype = C.c_int
+        l.orc_fuse.argtypes = [P, C.c_int, C.c_char_p, C.c_int]
         l.orc_count_positions.restype = C.c_int64
         l.orc_count_positions.argtypes = [C.c_int, P, P]
         l.orc_call.restype = C.c_int64
@@ -185,6 +187,31 @@ class Msa:
             if need <= cap:
                 return parse_phase_report(buf.value.decode())
             cap = int(need)
+
+    def col_insertions(self, col):
+        """MSAColumn::Insertions() of window column col: {string: count}."""
+        cap = 1 << 16
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = lib().orc_col_insertions(self.h, int(col), buf, cap)
+            if n >= 0:
+                break
+            cap = -n + 1
+        out = {}
+        for line in buf.value.decode().splitlines():
+            s, c = line.split("\t")
+            out[s] = int(c)
+        return out
+
+    def fuse(self, min_coverage=50):
+        """Fuse::CreateConsensus on this MSA (src/tools/Fuse.cpp:70-97)."""
+        cap = self.W * 70 + 64
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = lib().orc_fuse(self.h, int(min_coverage), buf, cap)
+            if n >= 0:
+                return buf.value.decode()
+            cap = -n + 1
 
     def close(self):
         if self.h:
