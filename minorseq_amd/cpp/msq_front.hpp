@@ -14,8 +14,9 @@
 //   PacBio::Juliet::VariantGene                include/pacbio/juliet/VariantGene.h:49-81 (msa context as plain structs)
 //   PacBio::Juliet::AminoAcidCaller            include/pacbio/juliet/AminoAcidCaller.h:90-154 (CallVariants + store policy)
 // Per-read rows (MSAByRow::Rows()/NameToRow) are not materialised: PhaseVariants, their one consumer, gets the
-// codons it asks for from the device (MSAByRow::PhaseKeys).  Not mirrored:
-// per-column insertion maps, JSON serialisation, TargetConfig JSON parsing.
+// codons it asks for from the device (MSAByRow::PhaseKeys).  Also here: the JSON report
+// (msq_json.hpp), the --msa / --mode-error writers, MSAColumn::Insertions() and PacBio::Fuse::Fuse
+// (include/pacbio/fuse/Fuse.h:50-72).  Not mirrored: TargetConfig JSON parsing, the HTML report.
 //
 // Errors: ABI status codes come back as the reference's exceptions -- std::runtime_error("Unexpected cigar ..") /
 // ("Unexpected base ..") (src/MSA.cpp:85,182), std::out_of_range (referenceSequence.substr,
@@ -184,22 +185,29 @@ class MSAByColumn;
 
 /// MSAByRow: the pileup.  The reads are packed (msq_pack_reads), uploaded, and one msq_pileup builds both count
 /// matrices on the GPU; CodonsAt() and MSAByColumn read them back.
+/// Which per-column insertion histograms (MSARow::Insertions -> MSAColumn::Insertions(), src/MSA.cpp:88-90,151-156)
+/// an MSAByRow collects.  juliet never reads them (None); fuse only reads strings above half a column's coverage
+/// (Majority: the columns whose insertion count can reach that); All = every column, as the reference always does.
+enum class InsertionMode { None, Majority, All };
+
 class MSAByRow  // include/pacbio/data/MSA.h:59-93
 {
 public:
     MSAByRow() = default;
-    MSAByRow(const std::vector<std::shared_ptr<Data::ArrayRead>>& reads)
+    MSAByRow(const std::vector<std::shared_ptr<Data::ArrayRead>>& reads, InsertionMode insertions = InsertionMode::None)
     {
         std::vector<const ArrayRead*> p;
         for (const auto& r : reads) p.push_back(r.get());
-        Build(p);
+        Build(p, insertions);
     }
-    MSAByRow(const std::vector<Data::ArrayRead>& reads)
+    MSAByRow(const std::vector<Data::ArrayRead>& reads, InsertionMode insertions = InsertionMode::None)
     {
         std::vector<const ArrayRead*> p;
         for (const auto& r : reads) p.push_back(&r);
-        Build(p);
+        Build(p, insertions);
     }
+    /// Per window column the insertion strings and their row counts (empty vector with InsertionMode::None).
+    const std::vector<std::map<std::string, int>>& Insertions() const { return insertions_; }
     /// The left-most / right-most position of all reads, 1-based after construction (src/MSA.cpp:107-108).
     int BeginPos() const { return beginPos_; }
     int EndPos() const { return endPos_; }
@@ -244,7 +252,45 @@ public:
     }
 
 private:
-    void Build(const std::vector<const ArrayRead*>& reads)
+    // The insertion histogram: count the recorded insertions per column on the GPU, pick the columns
+    // that matter, fetch their (column, string) records and add them up.
+    void CollectInsertions(msq_ctx* ctx, const msq_packed_reads* view, int32_t b0, InsertionMode mode)
+    {
+        insertions_.assign((size_t)width_, {});
+        if (width_ == 0) return;
+        Msq::DeviceBuffer<uint32_t> dTotal((size_t)width_);
+        Msq::Check(msq_insertion_counts(ctx, view, b0, width_, dTotal.get()));
+        const std::vector<uint32_t> total = dTotal.ToHost();
+        std::vector<uint32_t> filter(((size_t)width_ + 31) / 32, 0);
+        uint64_t capacity = 0;
+        for (int c = 0; c < width_; ++c) {
+            if (total[c] == 0) continue;
+            if (mode == InsertionMode::Majority) {  // a string needs count > Coverage() * 0.5 (src/tools/Fuse.cpp:107-110)
+                uint32_t coverage = 0;
+                for (int t = 0; t < 6; ++t) coverage += nuc_[(size_t)c * 6 + t];
+                if (!(total[c] > coverage * 0.5)) continue;
+            }
+            filter[c >> 5] |= 1u << (c & 31);
+            capacity += total[c];
+        }
+        if (capacity == 0) return;
+        Msq::DeviceBuffer<uint32_t> dFilter(filter.size());
+        Msq::Check(msq_memcpy_h2d(ctx, dFilter.get(), filter.data(), filter.size() * sizeof(uint32_t)));
+        Msq::DeviceBuffer<msq_insertion> dRecords(capacity);
+        uint64_t n = 0;
+        Msq::Check(msq_insertion_records(ctx, view, b0, width_, dFilter.get(), dRecords.get(), capacity, &n));
+        const std::vector<msq_insertion> records = dRecords.ToHost();
+        static const char nt[] = "ACGT";
+        std::string s;
+        for (uint64_t k = 0; k < n; ++k) {
+            const msq_insertion& r = records[k];
+            s.assign(r.len, 'A');
+            for (uint32_t i = 0; i < r.len; ++i) s[i] = nt[((i < 32 ? r.seq_lo >> (2 * i) : r.seq_hi >> (2 * (i - 32)))) & 3];
+            ++insertions_[(size_t)r.col][s];
+        }
+    }
+
+    void Build(const std::vector<const ArrayRead*>& reads, InsertionMode insertionMode)
     {
         const QvThresholds qv;  // member qvThresholds_ of the reference: read from the environment per MSA (MSA.h:82)
         numReads_ = reads.size();
@@ -274,7 +320,9 @@ private:
         msq_ctx* ctx = Msq::Context();
         msq_packed_dev* dev = nullptr;
         // "Unexpected cigar ..." -> std::runtime_error
-        Msq::Check(msq_pack_reads_device(ctx, reads.size(), rs.data(), re.data(), ptr.data(), len.data(), 0, 0, 0, &dev));
+        // the insertion scan needs the genomic order inside each group (plain layout); the pileup takes both
+        const uint32_t packFlags = insertionMode == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
+        Msq::Check(msq_pack_reads_device(ctx, reads.size(), rs.data(), re.data(), ptr.data(), len.data(), packFlags, 0, 0, &dev));
         dev_.reset(dev, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // kept for PhaseKeys
         {
             int32_t b0 = 0, e0 = 0;
@@ -289,6 +337,7 @@ private:
             Msq::Check(msq_pileup_check(ctx));  // "Unexpected base ..." -> std::runtime_error
             nuc_ = dNuc_->ToHost();
             codon_ = dCodon_->ToHost();
+            if (insertionMode != InsertionMode::None) CollectInsertions(ctx, msq_packed_dev_view(dev), b0, insertionMode);
         }
         if (!reads.empty()) {  // ++beginPos_, ++endPos_ (src/MSA.cpp:107-108)
             ++beginPos_;
@@ -308,6 +357,7 @@ private:
     std::shared_ptr<msq_packed_dev> dev_;  // the packed reads stay in HBM for the phasing pass
     msq_qv_thresholds thr_{-1, -1, -1, -1};
     std::vector<std::string> names_;
+    std::vector<std::map<std::string, int>> insertions_;
 };
 
 /// A single MSA column: counts per nucleotide {A, C, G, T, -, N}.
@@ -338,9 +388,13 @@ public:
         return m == 5 ? ' ' : bases[m];
     }
     int RefPos() const { return refPos_; }
+    /// Insertions and respective counts (MSA.h:179-180, MSA.inl:101-103); filled when the MSAByRow collected them.
+    const std::map<std::string, int>& Insertions() const { return insertions_; }
+    void IncInsertion(const std::string& seq) { insertions_[seq]++; }
 
 private:
     std::array<int, 6> counts_{{0, 0, 0, 0, 0, 0}};
+    std::map<std::string, int> insertions_;
     int refPos_ = -1;
     friend class MSAByColumn;
 };
@@ -362,6 +416,7 @@ public:
         for (int i = 0; i < size; ++i) {
             counts.emplace_back(pos++);
             for (int t = 0; t < 6; ++t) counts.back().counts_[t] = static_cast<int>(nuc[(size_t)i * 6 + t]);
+            if (!msaRows.Insertions().empty()) counts.back().insertions_ = msaRows.Insertions()[(size_t)i];  // MSA.cpp:88-90
         }
     }
     MSAColumn& operator[](int i) const { return const_cast<MSAColumn&>(counts[i - beginPos_]); }
@@ -979,4 +1034,85 @@ struct JulietWorkflow
     }
 };
 }  // namespace Juliet
+
+namespace Fuse {
+/// fuse's consensus on the same pileup (include/pacbio/fuse/Fuse.h:50-72, src/tools/Fuse.cpp:60-140): per column
+/// the majority base, plus the most abundant in-frame insertion where it is carried by more than half the column's
+/// coverage, strongest first, suppressing weaker ones within 20 positions.  The pileup and the insertion histogram
+/// come from the GPU (MSAByRow with InsertionMode::Majority); the few statements below are the host part.
+class Fuse
+{
+public:
+    explicit Fuse(const std::vector<Data::ArrayRead>& arrayReads) { consensusSequence_ = CreateConsensus(arrayReads); }
+    /// the (ccsInput, minCoverage) constructor of the reference with the reads already decoded
+    /// (FetchAlignedReads, src/tools/Fuse.cpp:142-153; see msq_bam.hpp for the BAM side)
+    Fuse(const std::vector<Data::ArrayRead>& arrayReads, int minCoverage) : minCoverageRecommended_(minCoverage)
+    {
+        consensusSequence_ = CreateConsensus(arrayReads);
+    }
+    std::string ConsensusSequence() const { return consensusSequence_; }
+
+private:
+    std::string CreateConsensus(const std::vector<Data::ArrayRead>& arrayReads) const  // Fuse.cpp:70-97
+    {
+        if (arrayReads.empty()) throw std::runtime_error("Empty input. Could not find records.");
+        const Data::MSAByRow rows(arrayReads, Data::InsertionMode::Majority);
+        const Data::MSAByColumn msa(rows);
+        const int actualCoverage = static_cast<int>(arrayReads.size());
+        const int minCoverage = actualCoverage < minCoverageRecommended_ ? 1 : minCoverageRecommended_;  // permissive mode
+        auto posInsCov = CollectInsertions(msa);
+        std::map<int, std::string> posIns;
+        while (!posInsCov.empty()) posIns.insert(FindInsertions(&posInsCov));
+        std::string consensus;
+        for (const auto& c : msa) {
+            const auto ins = posIns.find(c.RefPos());
+            if (ins != posIns.cend()) consensus += ins->second;
+            if (c.Coverage() >= minCoverage) {
+                const char maxBase = c.MaxBase();
+                if (maxBase != '-' && maxBase != ' ') consensus += maxBase;
+            }
+        }
+        return consensus;
+    }
+    /// RefPos -> (insertion, count): the most abundant insertion whose length is a multiple of three and whose count
+    /// exceeds half the column's coverage; first in string order among equals (Fuse.cpp:99-119)
+    std::map<int, std::pair<std::string, int>> CollectInsertions(const Data::MSAByColumn& msa) const
+    {
+        std::map<int, std::pair<std::string, int>> posInsCov;
+        for (const auto& c : msa) {
+            const double minInsertionCoverage = c.Coverage() * minInsertionCoverageFreq_;
+            int best = -1;
+            const std::string* bestSeq = nullptr;
+            for (const auto& ins_count : c.Insertions()) {
+                if (ins_count.first.size() % 3 != 0) continue;
+                if (ins_count.second > best && ins_count.second > minInsertionCoverage) {
+                    best = ins_count.second;
+                    bestSeq = &ins_count.first;
+                }
+            }
+            if (bestSeq) posInsCov[c.RefPos()] = std::make_pair(*bestSeq, best);
+        }
+        return posInsCov;
+    }
+    /// takes the best-covered entry (the left-most among equals) out of the map together with everything in
+    /// [pos - windowSize, pos + windowSize) (Fuse.cpp:121-140)
+    std::pair<int, std::string> FindInsertions(std::map<int, std::pair<std::string, int>>* posInsCov, int windowSize = 20) const
+    {
+        int argMax = -1, maxCov = -1;
+        std::string ins;
+        for (const auto& kv : *posInsCov)
+            if (kv.second.second > maxCov) {
+                maxCov = kv.second.second;
+                argMax = kv.first;
+                ins = kv.second.first;
+            }
+        posInsCov->erase(posInsCov->lower_bound(std::max(0, argMax - windowSize)), posInsCov->lower_bound(argMax + windowSize));
+        return std::make_pair(argMax, ins);
+    }
+
+    const int minCoverageRecommended_ = 50;
+    const double minInsertionCoverageFreq_ = 0.5;
+    std::string consensusSequence_;
+};
+}  // namespace Fuse
 }  // namespace PacBio

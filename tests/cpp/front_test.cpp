@@ -174,6 +174,64 @@ int main()
         DumpPhase("rich_default_subqv42", aac);
         DumpReports("rich_default_subqv42", aac);
     }
+    // fuse (src/tools/Fuse.cpp:60-140): planted insertions -- in frame and strong, in frame but weaker and within 20
+    // positions of a stronger one, out of frame, below half the coverage -- a majority deletion, noise; then too few reads
+    for (const int n_reads : {400, 30}) {
+        const int W = 300, start0 = 7;
+        std::string fref;
+        for (int i = 0; i < W; ++i) fref += "ACGT"[rnd() % 4];
+        std::printf("READS fuse%d\n", n_reads);
+        std::vector<Data::ArrayRead> reads;
+        for (int r = 0; r < n_reads; ++r) {
+            int a = 0, b = W;
+            if (r > 0 && urand() < 0.2) {
+                a = (int)(rnd() % (W / 2));
+                b = a + 1 + (int)(rnd() % (W - a));
+            }
+            std::vector<Data::ArrayBase> bases;
+            auto insert = [&](const char* s) {
+                for (const char* p = s; *p; ++p) bases.emplace_back('I', *p, (uint8_t)(rnd() % 94));
+            };
+            for (int c = a; c < b; ++c) {
+                if (c == 100 && urand() < 0.8) insert("GGA");
+                if (c == 110 && urand() < 0.6) insert("TTTCCC");
+                if (c == 200 && urand() < 0.9) insert("AC");
+                if (c == 250 && urand() < 0.4) insert("CAT");
+                if (c == 280 && urand() < 0.7) insert(urand() < 0.5 ? "AAA" : "AAC");
+                if (c > a && urand() < 0.01) insert(urand() < 0.5 ? "G" : "TCA");
+                if (c == 50 && urand() < 0.7)
+                    bases.emplace_back('D', '-', (uint8_t)0);
+                else if (urand() < 0.01)
+                    bases.emplace_back('X', fref[c] == 'C' ? 'T' : 'C', (uint8_t)(rnd() % 94));
+                else
+                    bases.emplace_back('=', fref[c], (uint8_t)(rnd() % 94));
+            }
+            if (urand() < 0.1) insert("TT");  // trailing: dropped
+            std::printf("READ %d %d ", start0 + a, start0 + b);
+            for (const auto& x : bases) std::putchar(x.Cigar);
+            std::putchar(' ');
+            for (const auto& x : bases) std::putchar(x.Nucleotide);
+            std::putchar(' ');
+            for (size_t i = 0; i < bases.size(); ++i) std::printf("%s%d", i ? "," : "", bases[i].QualQV);
+            std::putchar('\n');
+            reads.emplace_back(r, "read/" + std::to_string(r), start0 + a, start0 + b, bases);
+        }
+        const Fuse::Fuse fuse(reads);
+        std::printf("FUSE fuse%d 50 %s\n", n_reads, fuse.ConsensusSequence().c_str());
+        const Fuse::Fuse fuse10(reads, 10);
+        std::printf("FUSE fuse%d 10 %s\n", n_reads, fuse10.ConsensusSequence().c_str());
+        const Data::MSAByRow all(reads, Data::InsertionMode::All);  // what MSAColumn::Insertions() holds in the reference
+        const Data::MSAByColumn cols(all);
+        int k = 0;
+        for (const auto& c : cols) {
+            if (!c.Insertions().empty()) {
+                std::printf("INS fuse%d %d", n_reads, k);
+                for (const auto& kv : c.Insertions()) std::printf(" %s:%d", kv.first.c_str(), kv.second);
+                std::putchar('\n');
+            }
+            ++k;
+        }
+    }
     // exceptions keep the reference's types and texts
     try {
         std::vector<Data::ArrayRead> bad{Data::ArrayRead(0, "x", 0, 3, {Data::ArrayBase('=', 'A', 9), Data::ArrayBase('N', 'C', 9), Data::ArrayBase('=', 'G', 9)})};
@@ -199,6 +257,12 @@ int main()
         std::printf("ERR none\n");
     } catch (const std::out_of_range& e) {
         std::printf("ERR out_of_range %s\n", e.what());
+    }
+    try {
+        const Fuse::Fuse none(std::vector<Data::ArrayRead>{});
+        std::printf("ERR none\n");
+    } catch (const std::runtime_error& e) {
+        std::printf("ERR runtime_error %s\n", e.what());
     }
     return 0;
 }

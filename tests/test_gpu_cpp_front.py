@@ -47,6 +47,12 @@ def dump():
         if t[0] == "JSONFORM":
             d["jsonform"] = line[len("JSONFORM "):]
             continue
+        if t[0] == "FUSE":
+            d.setdefault("fuse", {})[(t[1], int(t[2]))] = t[3] if len(t) > 3 else ""
+            continue
+        if t[0] == "INS":
+            d.setdefault("ins", {}).setdefault(t[1], {})[int(t[2])] = {kv.split(":")[0]: int(kv.split(":")[1]) for kv in t[3:]}
+            continue
         if t[0] == "PHASE":
             cur_phase = d["phase"].setdefault(t[1], {"vpos": [], "hit": [], "report": []})
         elif t[0] == "ENDPHASE":
@@ -251,6 +257,7 @@ def test_exceptions_keep_reference_types(dump):
     assert e[0] == "runtime_error Unexpected cigar 78"   # std::to_string('N'), src/MSA.cpp:182
     assert e[1] == "runtime_error Unexpected base"       # src/MSA.cpp:85
     assert e[2].startswith("out_of_range")               # referenceSequence.substr, src/AminoAcidCaller.cpp:446
+    assert e[3] == "runtime_error Empty input. Could not find records."  # src/tools/Fuse.cpp:72
 
 
 @pytest.mark.parametrize("case", ["noconfig", "config", "rich_default_subqv42"])
@@ -306,6 +313,36 @@ def test_json_report(dump, case):
     cnt = rep["haplotype_read_counts"]
     assert [cnt[k] for k in ("healthy_reported", "healthy_low_coverage", "all_damaged", "marginal_with_gaps",
                              "marginal_with_heteroduplexes", "marginal_partial_reads")] == rp["cnt"]
+
+
+@pytest.mark.parametrize("name", ["fuse400", "fuse30"])
+def test_fuse_consensus_and_insertion_maps(dump, name):
+    """PacBio::Fuse::Fuse (src/tools/Fuse.cpp:60-140) and MSAColumn::Insertions() through the front -- pileup and
+    insertion histogram on the GPU -- against the oracle's restatement on the same reads (parity
+    unpinned: the reference holds no fuse fixture)."""
+    m = orc.Msa(to_reads(dump["reads"][name], False))
+    for min_cov in (50, 10):
+        want = m.fuse(min_cov)
+        assert dump["fuse"][(name, min_cov)] == want
+    got = dump["ins"][name]
+    n_cols = 0
+    for c in range(m.W):
+        want = m.col_insertions(c)
+        assert got.get(c, {}) == want, c
+        n_cols += bool(want)
+    assert n_cols > 5
+    cons = dump["fuse"][(name, 50)]
+    if name == "fuse400":
+        # the planted structure: GGA (80 %) goes in, TTTCCC (60 %, 10 columns on) is suppressed by it, AC is out of
+        # frame, CAT stays below half, neither AAA nor AAC reaches half alone; column 50 is a majority deletion
+        nuc = m.nuc_counts()
+        base = lambda c: "ACGT-"[int(np.argmax(nuc[c]))]
+        plain = "".join(base(c) for c in range(m.W) if base(c) != "-")
+        assert len(cons) == len(plain) + 3 and base(50) == "-"
+        at = sum(1 for c in range(100) if base(c) != "-")
+        assert cons == plain[:at] + "GGA" + plain[at:]
+    else:
+        assert len(m.fuse(50)) > 0 and len(dump["reads"][name]) < 50  # permissive mode: minCoverage 1
 
 
 def test_json_serializer_fixed_points(dump):
