@@ -6,7 +6,11 @@
 
 A step is one pass of the hot path over one batch of synthetic reads already resident in HBM:
 window bounds -> zero the count matrices -> pileup (nucleotide + codon counts) -> [N > 1: RCCL all-reduce of the
-integer count matrices] -> CountNumberOfTests + per-(position, codon) Fisher cells.  N > 1 is weak scaling:
+integer count matrices] -> CountNumberOfTests + per-(position, codon) Fisher cells.  By default the window bounds
+stay in HBM between the bounds kernel and the pileup (msq_window_bounds_device / msq_pileup_device_window: the
+count matrices are sized from the set-up window, a wider window would raise a deferred error, and the bounds are
+compared with the set-up window after the timed loop); --host-bounds brings them back to the host every step, as
+MSAByRow's constructor does.  N > 1 is weak scaling:
 every rank holds its own shard of `reads` reads of one global sample (global read index = rank * reads + i),
 there is no data-path collective besides the count all-reduce the north star prescribes.
 
@@ -37,6 +41,9 @@ def parse():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
     ap.add_argument("--qualqv", type=int, default=-1, help="QUALQV threshold (env var of the reference); -1 = unset")
     ap.add_argument("--mode", default="auto", choices=["auto", "simple", "stream"])
+    ap.add_argument("--host-bounds", action="store_true", help="bring the window bounds back to the host every step "
+                    "(msq_window_bounds + msq_pileup) instead of leaving them in HBM (msq_window_bounds_device + "
+                    "msq_pileup_device_window, the default)")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)  # name:first:n -> prints the oracle's seconds
     ap.add_argument("--h2d-steps", type=int, default=0, help="also time K steps that first copy the packed reads from "
@@ -145,13 +152,26 @@ def main():
     em = abi.ErrorModel()
     abi.check(L.msq_error_model_default(C.byref(em)))
 
-    def step():
+    bounds = torch.zeros(2, dtype=torch.int32, device="cuda")  # {-begin0, end0}, device-resident
+
+    def step_host_bounds():  # the window comes back to the host every step, as MSAByRow's constructor needs it
         sharding.allreduce_bounds(*device.window_bounds(ctx, dr), "cuda")  # MSAByRow pass 1 (UpdateBoundaries)
         counts.zero_()
         abi.check(L.msq_pileup(ctx.h, dr.view, thr, b0, W, nuc.data_ptr(), codon.data_ptr(), mode))
         sharding.allreduce_counts(counts)  # N > 1: RCCL sum of the integer count matrices over xGMI
         abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
                                    plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))
+
+    def step_device_bounds():  # the same work with the window left in HBM: nothing in the step waits for the host
+        abi.check(L.msq_window_bounds_device(ctx.h, dr.view, bounds.data_ptr()))
+        sharding.allreduce_bounds_device(bounds)  # N > 1: one 2-int MAX
+        counts.zero_()
+        abi.check(L.msq_pileup_device_window(ctx.h, dr.view, thr, bounds.data_ptr(), W, nuc.data_ptr(), codon.data_ptr()))
+        sharding.allreduce_counts(counts)
+        abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
+                                   plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))
+
+    step = step_host_bounds if (a.host_bounds or a.mode == "simple") else step_device_bounds
 
     def barrier():
         if world > 1:
@@ -171,6 +191,8 @@ def main():
     dt = time.perf_counter() - t0
     abi.check(L.msq_pileup_check(ctx.h))
     abi.check(L.msq_call_check(ctx.h))
+    if step is step_device_bounds and bounds.tolist() != [-b0, e0]:
+        raise SystemExit("device-resident window bounds %s differ from the set-up window [%d, %d)" % (bounds.tolist(), b0, e0))
     ms = (C.c_float * a.steps)()
     n_ms = C.c_int32(0)
     abi.check(L.msq_timing_read(ctx.h, ms, a.steps, C.byref(n_ms)))
@@ -216,6 +238,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %d reads/GPU x %d columns (HXB2 pol, 1%% minors), QUALQV=%s" % (
                 wl.name, reads, W, "unset" if a.qualqv < 0 else a.qualqv), "mode": a.mode,
+                "window_bounds": "device-resident" if step is step_device_bounds else "host round trip per step",
                 "bases_per_gpu": int(n_bases), "codon_positions": plan.P, "number_of_tests": int(plan.n_tests.item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kernel_name, wl.name, reads, a.qualqv),

@@ -150,6 +150,11 @@ int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_sta
  * end0 = max ReferenceEnd (0-based; MSAByRow::BeginPos()/EndPos() report begin0+1 / end0+1, MSA.cpp:107-108).
  * No reads: begin0 = INT32_MAX, end0 = 0.  d_reads fields are device pointers.  Synchronises. */
 int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* begin0, int32_t* end0);
+/* The same bounds left in device memory, for callers that must not wait for the host (a stream of batches whose
+ * window is known from the target configuration, steps captured in a HIP graph, shards merged by a collective):
+ * d_bounds[0] = -begin0, d_bounds[1] = end0 -- negated so that ONE element-wise MAX all-reduce over the ranks
+ * yields the global window.  No reads: {-INT32_MAX, 0}.  Enqueued on the stream, does not synchronise. */
+int msq_window_bounds_device(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_bounds);
 
 /* MSAByRow::MSAByRow + MSAByColumn::MSAByColumn + MSAByRow::CodonsAt for every column
  * (src/MSA.cpp:55-92, 94-136, 144-219) as two dense count matrices, ADDED into the caller's buffers:
@@ -163,6 +168,13 @@ int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* be
 #define MSQ_PILEUP_STREAM 2   /* force the streaming bit-plane kernel (error if not applicable) */
 int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
                int32_t W, uint32_t* d_nuc, uint32_t* d_codon, int mode);
+/* msq_pileup whose window comes from device memory, as msq_window_bounds_device (and a MAX all-reduce) left it:
+ * window = [-d_bounds[0], d_bounds[1]).  The count matrices hold W_max columns; a wider window raises the
+ * deferred MSQ_ERR_WINDOW, columns beyond the window stay untouched.  No host synchronisation anywhere: bounds
+ * -> pileup -> msq_call_cells run back to back on the stream.  Streaming kernel only (reads without
+ * MSQ_READS_HAS_EXOTIC); otherwise MSQ_ERR_ARG.  Same reference lines as msq_pileup. */
+int msq_pileup_device_window(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,
+                             const int32_t* d_bounds, int32_t W_max, uint32_t* d_nuc, uint32_t* d_codon);
 /* Deferred device-side error of the pileups enqueued since the last check (MSQ_ERR_BASE / MSQ_ERR_WINDOW).
  * Synchronises. */
 int msq_pileup_check(msq_ctx* ctx);

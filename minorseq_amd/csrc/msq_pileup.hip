@@ -10,7 +10,8 @@
 #include <climits>
 
 int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr,
-                             int32_t win_begin0, int32_t W, uint32_t* d_nuc, uint32_t* d_codon, bool* handled);
+                             int32_t win_begin0, int32_t W, const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon,
+                             bool* handled);
 
 // ------------------------------------------------------------------------------------------ window bounds
 // MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:138-142).  out[0] = max over reads of ~key(start),
@@ -53,6 +54,43 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
     }
 }
 
+// The keyed maxima of all reads into the first 8 bytes of the context's scratch (enqueued, not waited for).
+static int launch_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, void** scratch)
+{
+    int rc = msq_scratch(ctx, 64, scratch);
+    if (rc != MSQ_OK) return rc;
+    MSQ_HIP(hipMemsetAsync(*scratch, 0, 8, ctx->stream));
+    if (d_reads->n_reads == 0) return MSQ_OK;
+    uint64_t blocks = (d_reads->n_reads / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : blocks > 128 ? 128 : blocks;  // few blocks: their same-address atomics serialise
+    hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_reads->ref_start,
+                       d_reads->ref_end, d_reads->n_reads, (uint32_t*)*scratch);
+    MSQ_HIP(hipGetLastError());
+    return MSQ_OK;
+}
+
+// {-begin0, end0} from the keyed maxima; no reads: begin0 = INT_MAX, end0 = 0 (MSA.h:83-84)
+__global__ void window_bounds_decode_kernel(const uint32_t* __restrict__ keyed, uint64_t n_reads, int32_t* __restrict__ out)
+{
+    const int32_t begin0 = n_reads ? (int32_t)(~keyed[0] ^ 0x80000000u) : INT_MAX;
+    const int32_t hi = n_reads ? (int32_t)(keyed[1] ^ 0x80000000u) : 0;
+    out[0] = -begin0;
+    out[1] = hi > 0 ? hi : 0;
+}
+
+extern "C" int msq_window_bounds_device(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_bounds)
+{
+    if (!ctx || !d_reads || !d_bounds) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds_device: NULL argument");
+    if (d_reads->n_reads && (!d_reads->ref_start || !d_reads->ref_end)) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds_device: NULL ref arrays");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    void* s = nullptr;
+    int rc = launch_window_bounds(ctx, d_reads, &s);
+    if (rc != MSQ_OK) return rc;
+    hipLaunchKernelGGL(window_bounds_decode_kernel, dim3(1), dim3(1), 0, ctx->stream, (const uint32_t*)s, d_reads->n_reads, d_bounds);
+    MSQ_HIP(hipGetLastError());
+    return MSQ_OK;
+}
+
 extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* begin0, int32_t* end0)
 {
     if (!ctx || !d_reads || !begin0 || !end0) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds: NULL argument");
@@ -62,14 +100,8 @@ extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, 
     if (d_reads->n_reads == 0) return MSQ_OK;
     if (!d_reads->ref_start || !d_reads->ref_end) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds: NULL ref arrays");
     void* s = nullptr;
-    int rc = msq_scratch(ctx, 64, &s);
+    int rc = launch_window_bounds(ctx, d_reads, &s);
     if (rc != MSQ_OK) return rc;
-    MSQ_HIP(hipMemsetAsync(s, 0, 8, ctx->stream));
-    uint64_t blocks = (d_reads->n_reads / 4 + 255) / 256;
-    blocks = blocks < 1 ? 1 : blocks > 128 ? 128 : blocks;  // few blocks: their same-address atomics serialise
-    hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_reads->ref_start,
-                       d_reads->ref_end, d_reads->n_reads, (uint32_t*)s);
-    MSQ_HIP(hipGetLastError());
     uint32_t res[2];
     MSQ_HIP(hipMemcpyAsync(res, s, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     MSQ_HIP(hipStreamSynchronize(ctx->stream));
@@ -162,13 +194,36 @@ extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const m
     MSQ_HIP(hipSetDevice(ctx->device));
     if (mode != MSQ_PILEUP_SIMPLE) {
         bool handled = false;
-        int rc = msq_pileup_stream_launch(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon, &handled);
+        int rc = msq_pileup_stream_launch(ctx, *d_reads, *thr, win_begin0, W, nullptr, d_nuc, d_codon, &handled);
         if (rc != MSQ_OK) return rc;
         if (handled) return MSQ_OK;
         if (mode == MSQ_PILEUP_STREAM)
             return msq_fail(MSQ_ERR_ARG, "msq_pileup: streaming kernel not applicable (W=%d, flags=%u)", W, d_reads->flags);
     }
     return launch_simple(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon, d_reads->n_reads);
+}
+
+extern "C" int msq_pileup_device_window(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,
+                                        const int32_t* d_bounds, int32_t W_max, uint32_t* d_nuc, uint32_t* d_codon)
+{
+    if (!ctx || !d_reads || !thr || !d_bounds) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: NULL argument");
+    if (W_max < 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: negative capacity %d", W_max);
+    if (d_reads->n_reads == 0 || W_max == 0) return MSQ_OK;
+    if (!d_nuc || !d_codon) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: NULL count matrix");
+    if (!d_reads->ref_start || !d_reads->group_off || !d_reads->bop) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: NULL read arrays");
+    if (((uintptr_t)d_reads->bop & 15u) != 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: bop must be 16-byte aligned");
+    if ((((uintptr_t)d_reads->qual | (uintptr_t)d_reads->delqv | (uintptr_t)d_reads->subqv | (uintptr_t)d_reads->insqv) & 15u) != 0)
+        return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: QV planes must be 16-byte aligned");
+    for (int k = 0; k < 4; ++k) {
+        const int32_t t = (&thr->qual)[k];
+        if (t < -1 || t > 255) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: QV threshold %d out of range", t);
+    }
+    MSQ_HIP(hipSetDevice(ctx->device));
+    bool handled = false;
+    int rc = msq_pileup_stream_launch(ctx, *d_reads, *thr, 0, W_max, d_bounds, d_nuc, d_codon, &handled);
+    if (rc != MSQ_OK) return rc;
+    if (!handled) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: needs the streaming kernel (flags=%u)", d_reads->flags);
+    return MSQ_OK;
 }
 
 extern "C" int msq_pileup_check(msq_ctx* ctx)

@@ -61,6 +61,8 @@ struct StreamArgs {
     uint64_t read_lo, read_hi;  // this launch covers reads [read_lo, read_hi)
     uint64_t n_batches;         // ceil((read_hi - read_lo) / 8)
     int32_t win_begin0, W;
+    const int32_t* d_bounds;  // NULL, or {-begin0, end0} in device memory (msq_window_bounds_device): the window is
+                              // read from there and W above is the capacity of the count matrices
     int32_t slab0;       // first window column of this launch's column slab (a multiple of 32)
     int32_t G;           // 32-column words of the slab (<= 128)
     int32_t RD;          // words per LDS row: a margin word, the slab's G words, two margin words, a zero pad word
@@ -384,7 +386,16 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     extern __shared__ __align__(16) uint32_t lds[];
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, NWV = T >> 6;
     const int wave = (int)uni((uint32_t)tid >> 6);   // tell the compiler it is wave-uniform: all stream control is scalar
-    const int RD = a.RD, G = a.G, W = a.W;
+    const int RD = a.RD, G = a.G;
+    uint32_t my_err = 0, exotic = 0;
+    int W = a.W;
+    int32_t win_begin0 = a.win_begin0;
+    if (a.d_bounds) {  // the window as the bounds kernel (and the all-reduce over the shards) left it in HBM
+        win_begin0 = -a.d_bounds[0];
+        const int w = a.d_bounds[1] - win_begin0;
+        if (w < 0 || w > W) my_err |= DEVERR_WINDOW;  // wider than the count matrices
+        W = w < 0 ? 0 : w < W ? w : W;
+    }
     const int slab0 = a.slab0, wbase = slab0 >> 5;            // window word of the slab's word 0
     const uint32_t slab_span = 32u * (uint32_t)(G + 1) + 31u;
     const int ROWB = RD * 4;                                  // dwords per row: [RD words][V X B0 B1]
@@ -393,7 +404,6 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     uint32_t* const wrow = lds + wave * WV;                   // this wave's rows
     uint16_t* const queue = reinterpret_cast<uint16_t*>(wrow + kRows * ROWB);
     uint32_t* const gl = lds + NWV * WV;                      // the workgroup's guide words [G + 3][4]
-    uint32_t my_err = 0, exotic = 0;
 
     // ---- phase-2 identity: in pass p this lane owns word cgp[p].  The last pass, when at most 32 words wide,
     // splits the batch's rows between the two halves of the wave (rows rbase .. rbase+3).
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     Slot<NP> sl[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) issue(sl[q]);
-    cs.init(a.group_off, a.ref_start, a.read_lo, a.read_hi, (uint32_t)a.n_batches, a.win_begin0, blockIdx.x * NWV + wave,
+    cs.init(a.group_off, a.ref_start, a.read_lo, a.read_hi, (uint32_t)a.n_batches, win_begin0, blockIdx.x * NWV + wave,
             gridDim.x * NWV, lane);
     // the batch's chunks, NS slots per trip in a fixed order: every wait for a slot sees the same NS - 1 younger
     // loads behind it
@@ -842,7 +852,7 @@ struct PhaseRequest {
 };
 
 static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
-                         uint32_t* d_nuc, uint32_t* d_codon, const PhaseRequest* phase, bool* handled)
+                         const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon, const PhaseRequest* phase, bool* handled)
 {
     *handled = false;
     if (R.flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
@@ -876,6 +886,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     a.bop = reinterpret_cast<const uint4*>(R.bop);
     a.win_begin0 = win_begin0;
     a.W = W;
+    a.d_bounds = d_bounds;
     a.normalized = (R.flags & MSQ_READS_NORMALIZED) ? 1u : 0u;
     a.nuc = d_nuc;
     a.codon = d_codon;
@@ -970,14 +981,14 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
 }
 
 int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
-                             int32_t W, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
+                             int32_t W, const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
 {
-    return stream_launch(ctx, R, thr, win_begin0, W, d_nuc, d_codon, nullptr, handled);
+    return stream_launch(ctx, R, thr, win_begin0, W, d_bounds, d_nuc, d_codon, nullptr, handled);
 }
 
 int msq_phase_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
                             int32_t W, int32_t n_pos, const int32_t* pos, uint16_t* d_keys, bool* handled)
 {
     const PhaseRequest req{n_pos, pos, d_keys};
-    return stream_launch(ctx, R, thr, win_begin0, W, nullptr, nullptr, &req, handled);
+    return stream_launch(ctx, R, thr, win_begin0, W, nullptr, nullptr, nullptr, &req, handled);
 }

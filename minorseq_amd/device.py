@@ -210,6 +210,24 @@ def window_bounds(ctx, dr):
     return b.value, e.value
 
 
+def window_bounds_device(ctx, dr, out=None):
+    """msq_window_bounds_device -> int32 tensor {-begin0, end0} in HBM (no host synchronisation)."""
+    if out is None:
+        out = torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", ctx.device))
+    abi.check(abi.lib().msq_window_bounds_device(ctx.h, dr.view, out.data_ptr()))
+    return out
+
+
+def pileup_device_window(ctx, dr, thr, bounds, W_max, nuc=None, codon=None, check=True):
+    """msq_pileup_device_window: the window is read from `bounds` (device), the matrices hold W_max columns."""
+    if nuc is None:
+        nuc, codon = alloc_counts(ctx, W_max)
+    abi.check(abi.lib().msq_pileup_device_window(ctx.h, dr.view, thr, bounds.data_ptr(), W_max, nuc.data_ptr(), codon.data_ptr()))
+    if check:
+        abi.check(abi.lib().msq_pileup_check(ctx.h))
+    return nuc, codon
+
+
 def alloc_counts(ctx, W):
     dev = torch.device("cuda", ctx.device)
     return (torch.zeros(max(W, 1) * 6, dtype=torch.int32, device=dev),

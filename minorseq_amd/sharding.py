@@ -27,6 +27,15 @@ def allreduce_bounds(begin0, end0, device):
     return -int(lo), int(hi)
 
 
+def allreduce_bounds_device(bounds):
+    """In-place global window of a device-resident {-begin0, end0} int32 pair (msq_window_bounds_device): one
+    element-wise MAX over the ranks, no host round trip."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        assert bounds.dtype == torch.int32 and bounds.numel() == 2
+        dist.all_reduce(bounds, op=dist.ReduceOp.MAX)
+    return bounds
+
+
 def allreduce_counts(counts):
     """In-place sum of the int32 count buffer over the ranks (the RCCL all-reduce of the north star)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -209,3 +209,41 @@ def test_phase_codon_keys(ctx, seed, W, rich, thr):
                 sym = np.full(n, 7, dtype=np.uint16)
             want |= sym << (3 * j)
         assert (got[:, k] == want).all(), (k, p)
+
+
+@pytest.mark.parametrize("name", sorted(EDGE) + ["random_indels", "random_rich", "wide"])
+def test_device_resident_window(ctx, name):
+    """msq_window_bounds_device + msq_pileup_device_window (no host round trip) against msq_window_bounds +
+    msq_pileup: the same bounds, the same counts -- with matrices of exactly the window's width and wider ones
+    (the extra columns stay zero); a window wider than the matrices raises the deferred MSQ_ERR_WINDOW."""
+    if name == "random_indels":
+        reads, thr = cases.random_reads(51, 300, 700, p_ins=0.05), (-1, -1, -1, -1)
+    elif name == "random_rich":
+        reads, thr = cases.random_reads(52, 200, 2300, rich=True, p_ins=0.05), (30, 20, 42, 25)
+    elif name == "wide":
+        reads, thr = cases.random_reads(53, 60, 5000), (-1, -1, -1, -1)
+    else:
+        reads, thr = EDGE[name]
+    q = abi.QvThresholds.make(*thr)
+    dr = device.upload(device.pack_host(reads), ctx.device)
+    b, e = device.window_bounds(ctx, dr)
+    bounds = device.window_bounds_device(ctx, dr)
+    assert bounds.tolist() == [-b, e]
+    if dr.n_reads == 0:
+        return
+    W = e - b
+    if dr.flags & abi.MSQ_READS_HAS_EXOTIC:  # the streaming kernel does not take these: a clear refusal
+        with pytest.raises(abi.MsqError) as err:
+            device.pileup_device_window(ctx, dr, q, bounds, W)
+        assert err.value.code == abi.MSQ_ERR_ARG
+        return
+    want_nuc, want_codon = device.pileup(ctx, dr, q, b, W)
+    for W_max in (W, W + 1, W + 77):
+        nuc, codon = device.pileup_device_window(ctx, dr, q, bounds, W_max)
+        nuc, codon = nuc.cpu().numpy().reshape(-1, 6), codon.cpu().numpy().reshape(-1, 64)
+        assert (nuc[:W] == want_nuc.cpu().numpy().reshape(-1, 6)[:W]).all() and not nuc[W:].any()
+        assert (codon[:W] == want_codon.cpu().numpy().reshape(-1, 64)[:W]).all() and not codon[W:].any()
+    if W > 3:
+        with pytest.raises(abi.MsqError) as err:
+            device.pileup_device_window(ctx, dr, q, bounds, W - 1)
+        assert err.value.code == abi.MSQ_ERR_WINDOW

@@ -35,6 +35,10 @@ def _rank_main(rank, world, port, n_reads, out_path):
         b0 = int(reads["ref_start"].min()) if count else 2 ** 31 - 1
         e0 = int(reads["ref_end"].max()) if count else 0
         gb0, ge0 = sharding.allreduce_bounds(b0, e0, "cpu")
+        # the device-resident form of the same merge ({-begin0, end0}, one MAX; what msq_window_bounds_device feeds)
+        pair = torch.tensor([-b0, e0], dtype=torch.int32)
+        sharding.allreduce_bounds_device(pair)
+        assert pair.tolist() == [-gb0, ge0]
         W = ge0 - gb0
         counts = torch.zeros(W * 70, dtype=torch.int32)
         if count:
