@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--host-bounds", action="store_true", help="bring the window bounds back to the host every step "
                     "(msq_window_bounds + msq_pileup) instead of leaving them in HBM (msq_window_bounds_device + "
                     "msq_pileup_device_window, the default)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the RCCL process group and issue "
+                    "the step's collectives even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)  # name:first:n -> prints the oracle's seconds
     ap.add_argument("--h2d-steps", type=int, default=0, help="also time K steps that first copy the packed reads from "
@@ -129,8 +131,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world > 1 or a.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        sharding.FORCE_COLLECTIVES = a.force_dist
 
     wl = synth.workload(a.workload)
     reads = a.reads or wl.n_reads
@@ -174,7 +179,7 @@ def main():
     step = step_host_bounds if (a.host_bounds or a.mode == "simple") else step_device_bounds
 
     def barrier():
-        if world > 1:
+        if world > 1 or a.force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -214,7 +219,7 @@ def main():
                 "host_bytes_per_step": int(sum(h.numel() * h.element_size() for h in host.values()))}
         del host
 
-    if world > 1:
+    if world > 1 or a.force_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
@@ -249,7 +254,7 @@ def main():
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or a.force_dist:
         dist.destroy_process_group()
 
 

@@ -9,6 +9,14 @@ turns per-shard window bounds (min ReferenceStart, max ReferenceEnd; src/MSA.cpp
 import torch
 import torch.distributed as dist
 
+# Rehearsal switch (bench.py --force-dist): issue the collectives even in a one-rank group, so that a one-GPU box
+# exercises the RCCL calls, dtypes and stream ordering of the N > 1 step.
+FORCE_COLLECTIVES = False
+
+
+def _collective():
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
 
 def shard_range(n_reads, rank, world):
     """Contiguous read range [first, first + count) of `rank`: sizes differ by at most one read."""
@@ -19,7 +27,7 @@ def shard_range(n_reads, rank, world):
 
 def allreduce_bounds(begin0, end0, device):
     """Global (min begin0, max end0) over the ranks; a rank without reads passes (INT32_MAX, 0)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collective():
         return int(begin0), int(end0)
     t = torch.tensor([-int(begin0), int(end0)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -30,7 +38,7 @@ def allreduce_bounds(begin0, end0, device):
 def allreduce_bounds_device(bounds):
     """In-place global window of a device-resident {-begin0, end0} int32 pair (msq_window_bounds_device): one
     element-wise MAX over the ranks, no host round trip."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective():
         assert bounds.dtype == torch.int32 and bounds.numel() == 2
         dist.all_reduce(bounds, op=dist.ReduceOp.MAX)
     return bounds
@@ -38,7 +46,7 @@ def allreduce_bounds_device(bounds):
 
 def allreduce_counts(counts):
     """In-place sum of the int32 count buffer over the ranks (the RCCL all-reduce of the north star)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective():
         assert counts.dtype == torch.int32 and counts.is_contiguous()
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     return counts
