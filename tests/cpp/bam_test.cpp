@@ -39,6 +39,15 @@ int main(int argc, char** argv)
                     const auto c0 = std::chrono::steady_clock::now();
                     Juliet::AminoAcidCaller aac(reads, error, s);
                     (rep ? call2_s : call_s) = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+                    if (rep) {
+                        const auto p0 = std::chrono::steady_clock::now();
+                        aac.PhaseVariants();
+                        const auto p1 = std::chrono::steady_clock::now();
+                        const std::string json = aac.JSON().dump(2);
+                        const auto p2 = std::chrono::steady_clock::now();
+                        std::printf("PHASE_S %.4f JSON_S %.4f haplotypes %zu json_bytes %zu\n", std::chrono::duration<double>(p1 - p0).count(),
+                                    std::chrono::duration<double>(p2 - p1).count(), aac.ReconstructedHaplotypes().size(), json.size());
+                    }
                 }
             }
             std::printf("TIMING threads %u file_bytes %zu bam_bytes %zu records %zu kept %zu bases %zu read_s %.4f inflate_s %.4f index_s %.4f parse_s %.4f "
