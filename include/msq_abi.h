@@ -144,6 +144,14 @@ typedef struct msq_array_base {
 int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
                           const msq_array_base* const* bases, const int64_t* n_bases, uint32_t pack_flags, int threads,
                           int64_t chunk_bases, msq_packed_dev** out);
+/* The same packer for a producer that has no ArrayBase arrays yet (a BAM decoder: BAMArrayRead's constructor,
+ * src/ArrayRead.cpp:53-99, writing straight into the staging buffer): instead of copying, the library calls
+ * fill(user, r, dst) for every read r -- each exactly once, from several threads at a time, in no particular
+ * order -- and the callee writes the read's n_bases[r] records to dst (pinned memory).  fill must not throw. */
+typedef void (*msq_fill_read_fn)(void* user, uint64_t read_index, msq_array_base* dst);
+int msq_pack_reads_device_fill(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                               const int64_t* n_bases, msq_fill_read_fn fill, void* user, uint32_t pack_flags,
+                               int threads, int64_t chunk_bases, msq_packed_dev** out);
 
 /* ----------------------------------------------------------------------------------------------- pileup
  * MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:96-97,138-142): begin0 = min ReferenceStart,

@@ -246,61 +246,10 @@ struct BamUtils
         if (threads == 0) threads = 1;
         regionStart = std::max(regionStart - 1, 0);
         regionEnd = std::max(regionEnd - 1, 0);
-        const auto t0 = Clock::now();
-        const MappedFile file(filePath);
-        const auto t1 = Clock::now();
-        const Bytes data = InflateBgzf(file, threads);
-        const size_t file_bytes = file.size();
-        const auto t2 = Clock::now();
-        if (data.size() < 12 || std::memcmp(data.data(), "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file: " + filePath);
-        size_t off = 4;
-        const size_t l_text = U32(&data[off]);
-        if (off + 4 + l_text + 4 > data.size()) throw std::runtime_error("truncated BAM header");
-        const std::vector<std::pair<std::string, std::string>> readGroups =
-            ReadGroupChemistries(std::string(reinterpret_cast<const char*>(&data[off + 4]), l_text));
-        off += 4 + l_text;
-        const size_t n_ref = U32(&data[off]);
-        off += 4;
-        for (size_t r = 0; r < n_ref; ++r) {
-            if (off + 4 > data.size()) throw std::runtime_error("truncated BAM header");
-            const size_t l_name = U32(&data[off]);
-            off += 4 + l_name + 4;
-        }
-        // pass 1 (cheap, sequential): record offsets, filters, idx of the kept ones
-        struct Kept
-        {
-            size_t off;  // of the record body
-            size_t block_size;
-            int64_t ref_start, ref_end;
-        };
-        std::vector<Kept> kept;
-        size_t n_records = 0;
-        while (off + 4 <= data.size()) {
-            const size_t block_size = U32(&data[off]);
-            const uint8_t* rec = &data[off + 4];
-            const size_t body = off + 4;
-            off += 4 + block_size;
-            if (off > data.size() || block_size < 32) throw std::runtime_error("truncated BAM record");
-            ++n_records;
-            const size_t l_read_name = rec[8];
-            const size_t n_cigar = U16(rec + 12);
-            const uint16_t flag = U16(rec + 14);
-            const size_t l_seq = U32(rec + 16);
-            if (32 + l_read_name + 4 * n_cigar + (l_seq + 1) / 2 + l_seq > block_size) throw std::runtime_error("malformed BAM record");
-            if (flag & 0x800) continue;  // IsSupplementaryAlignment (BamUtils.cpp:69)
-            if (flag & 0x100) continue;  // !IsPrimaryAlignment (BamUtils.cpp:70)
-            if (flag & 0x4) continue;    // unmapped: no reference interval to overlap
-            const uint8_t* cigar = rec + 32 + l_read_name;
-            int64_t ref_len = 0;
-            for (size_t k = 0; k < n_cigar; ++k) {
-                const uint32_t c = U32(cigar + 4 * k);
-                const int op = c & 15;
-                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
-            }
-            const int64_t ref_start = I32(rec + 4), ref_end = ref_start + ref_len;
-            if (!(ref_start < regionEnd && ref_end > regionStart)) continue;  // BamUtils.cpp:71
-            kept.push_back({body, block_size, ref_start, ref_end});
-        }
+        const Loaded loaded = Load(filePath, regionStart, regionEnd, threads);
+        const Bytes& data = loaded.data;
+        const std::vector<Kept>& kept = loaded.kept;
+        const auto& readGroups = loaded.readGroups;
         const auto t3 = Clock::now();
         // pass 2 (parallel): one ArrayRead per kept record
         std::vector<std::shared_ptr<Data::ArrayRead>> returnList(kept.size());
@@ -329,19 +278,145 @@ struct BamUtils
         }
         const auto t4 = Clock::now();
         if (timings) {
-            timings->read = secs(t0, t1);
-            timings->inflate = secs(t1, t2);
-            timings->index = secs(t2, t3);
+            timings->read = loaded.t_read;
+            timings->inflate = loaded.t_inflate;
+            timings->index = loaded.t_index;
             timings->parse = secs(t3, t4);
-            timings->file_bytes = file_bytes;
+            timings->file_bytes = loaded.file_bytes;
             timings->bam_bytes = data.size();
-            timings->records = n_records;
+            timings->records = loaded.n_records;
             timings->kept = kept.size();
         }
         return returnList;
     }
 
+    /// The same reads as BamToArrayReads, as a Data::ReadSource: names, reference intervals and base counts are
+    /// worked out here (run arithmetic on the cigars); the ArrayBases of a read are decoded only when the device
+    /// packer asks for them, straight into its pinned staging buffer -- no ArrayRead objects, no per-read allocation.
+    /// `chemistries` receives the distinct SequencingChemistry() strings in order of appearance (juliet refuses more
+    /// than one, src/tools/JulietWorkflow.cpp:144-148).
+    static Data::ReadSource BamToReadSource(const std::string& filePath, int regionStart, int regionEnd,
+                                            unsigned threads = std::thread::hardware_concurrency(), BamTimings* timings = nullptr,
+                                            std::vector<std::string>* chemistries = nullptr)
+    {
+        using Clock = std::chrono::steady_clock;
+        if (threads == 0) threads = 1;
+        regionStart = std::max(regionStart - 1, 0);
+        regionEnd = std::max(regionEnd - 1, 0);
+        const auto loaded = std::make_shared<const Loaded>(Load(filePath, regionStart, regionEnd, threads));
+        const auto t3 = Clock::now();
+        Data::ReadSource source;
+        const size_t n = loaded->kept.size();
+        source.names.reserve(n);
+        source.referenceStart.reserve(n);
+        source.referenceEnd.reserve(n);
+        source.numBases.reserve(n);
+        for (const Kept& k : loaded->kept) {
+            const uint8_t* rec = &loaded->data[k.off];
+            source.names.emplace_back(reinterpret_cast<const char*>(rec + 32));
+            source.referenceStart.push_back((int32_t)std::max<int64_t>(k.ref_start, regionStart));
+            source.referenceEnd.push_back((int32_t)std::min<int64_t>(k.ref_end, regionEnd));
+            source.numBases.push_back(CountBases(rec, k.ref_start, k.ref_end, regionStart, regionEnd));
+            if (chemistries) {
+                const std::string chem = ChemistryOf(rec, k.block_size, loaded->readGroups);
+                if (std::find(chemistries->begin(), chemistries->end(), chem) == chemistries->end()) chemistries->push_back(chem);
+            }
+        }
+        source.fill = [loaded, regionStart, regionEnd, filePath](uint64_t read, Data::ArrayBase* dst) {
+            const Kept& k = loaded->kept[read];
+            DecodeBases(&loaded->data[k.off], k.block_size, k.ref_start, k.ref_end, regionStart, regionEnd, filePath,
+                        [&dst](const Data::ArrayBase& b) { *dst++ = b; });
+        };
+        if (timings) {
+            timings->read = loaded->t_read;
+            timings->inflate = loaded->t_inflate;
+            timings->index = loaded->t_index + std::chrono::duration<double>(Clock::now() - t3).count();
+            timings->parse = 0;  // the decode happens inside the packer
+            timings->file_bytes = loaded->file_bytes;
+            timings->bam_bytes = loaded->data.size();
+            timings->records = loaded->n_records;
+            timings->kept = n;
+        }
+        return source;
+    }
+
 private:
+    struct Kept  // a record that passed the filters
+    {
+        size_t off;  // of the record body in the inflated stream
+        size_t block_size;
+        int64_t ref_start, ref_end;
+    };
+    struct Loaded
+    {
+        detail::Bytes data{0};
+        std::vector<Kept> kept;
+        std::vector<std::pair<std::string, std::string>> readGroups;
+        size_t n_records = 0, file_bytes = 0;
+        double t_read = 0, t_inflate = 0, t_index = 0;
+    };
+    /// map + inflate + header + pass 1 (cheap, sequential): record offsets and filters; regionStart / regionEnd 0-based here
+    static Loaded Load(const std::string& filePath, int regionStart, int regionEnd, unsigned threads)
+    {
+        using namespace detail;
+        using Clock = std::chrono::steady_clock;
+        auto secs = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        const auto t0 = Clock::now();
+        const MappedFile file(filePath);
+        const auto t1 = Clock::now();
+        Loaded L;
+        L.data = InflateBgzf(file, threads);
+        const Bytes& data = L.data;
+        L.file_bytes = file.size();
+        const auto t2 = Clock::now();
+        if (data.size() < 12 || std::memcmp(data.data(), "BAM\1", 4) != 0) throw std::runtime_error("not a BAM file: " + filePath);
+        size_t off = 4;
+        const size_t l_text = U32(&data[off]);
+        if (off + 4 + l_text + 4 > data.size()) throw std::runtime_error("truncated BAM header");
+        L.readGroups =
+            ReadGroupChemistries(std::string(reinterpret_cast<const char*>(&data[off + 4]), l_text));
+        off += 4 + l_text;
+        const size_t n_ref = U32(&data[off]);
+        off += 4;
+        for (size_t r = 0; r < n_ref; ++r) {
+            if (off + 4 > data.size()) throw std::runtime_error("truncated BAM header");
+            const size_t l_name = U32(&data[off]);
+            off += 4 + l_name + 4;
+        }
+        // pass 1 (cheap, sequential): record offsets, filters, idx of the kept ones
+        while (off + 4 <= data.size()) {
+            const size_t block_size = U32(&data[off]);
+            const uint8_t* rec = &data[off + 4];
+            const size_t body = off + 4;
+            off += 4 + block_size;
+            if (off > data.size() || block_size < 32) throw std::runtime_error("truncated BAM record");
+            ++L.n_records;
+            const size_t l_read_name = rec[8];
+            const size_t n_cigar = U16(rec + 12);
+            const uint16_t flag = U16(rec + 14);
+            const size_t l_seq = U32(rec + 16);
+            if (32 + l_read_name + 4 * n_cigar + (l_seq + 1) / 2 + l_seq > block_size) throw std::runtime_error("malformed BAM record");
+            if (flag & 0x800) continue;  // IsSupplementaryAlignment (BamUtils.cpp:69)
+            if (flag & 0x100) continue;  // !IsPrimaryAlignment (BamUtils.cpp:70)
+            if (flag & 0x4) continue;    // unmapped: no reference interval to overlap
+            const uint8_t* cigar = rec + 32 + l_read_name;
+            int64_t ref_len = 0;
+            for (size_t k = 0; k < n_cigar; ++k) {
+                const uint32_t c = U32(cigar + 4 * k);
+                const int op = c & 15;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+            }
+            const int64_t ref_start = I32(rec + 4), ref_end = ref_start + ref_len;
+            if (!(ref_start < regionEnd && ref_end > regionStart)) continue;  // BamUtils.cpp:71
+            L.kept.push_back({body, block_size, ref_start, ref_end});
+        }
+        const auto t3 = Clock::now();
+        L.t_read = secs(t0, t1);
+        L.t_inflate = secs(t1, t2);
+        L.t_index = secs(t2, t3);
+        return L;
+    }
+
     /// (@RG ID, "BINDINGKIT/SEQUENCINGKIT/BASECALLERVERSION") of every read group in the header text
     static std::vector<std::pair<std::string, std::string>> ReadGroupChemistries(const std::string& text)
     {
@@ -378,10 +453,65 @@ private:
         return out;
     }
 
+    static std::string ChemistryOf(const uint8_t* rec, size_t block_size, const std::vector<std::pair<std::string, std::string>>& readGroups)
+    {
+        using namespace detail;
+        const size_t l_read_name = rec[8], n_cigar = U16(rec + 12), l_seq = U32(rec + 16);
+        const uint8_t* tags = rec + 32 + l_read_name + 4 * n_cigar + (l_seq + 1) / 2 + l_seq;
+        const uint8_t* rg = nullptr;
+        size_t nrg = 0;
+        std::string chemistry;
+        if (FindZTag(tags, rec + block_size, 'R', 'G', &rg, &nrg)) {
+            const std::string id(reinterpret_cast<const char*>(rg), nrg);
+            for (const auto& g : readGroups)
+                if (g.first == id) chemistry = g.second;
+        }
+        return chemistry;
+    }
+
     static std::shared_ptr<Data::ArrayRead> DecodeRecord(const uint8_t* rec, size_t block_size, int64_t ref_start, int64_t ref_end,
                                                          int regionStart, int regionEnd, int idx,
                                                          const std::vector<std::pair<std::string, std::string>>& readGroups,
                                                          const std::string& filePath)
+    {
+        const int64_t clip_lo = std::max<int64_t>(ref_start, regionStart), clip_hi = std::min<int64_t>(ref_end, regionEnd);
+        std::vector<Data::ArrayBase> bases;
+        bases.reserve((size_t)(clip_hi - clip_lo) + 16);
+        DecodeBases(rec, block_size, ref_start, ref_end, regionStart, regionEnd, filePath, [&](const Data::ArrayBase& b) { bases.push_back(b); });
+        return std::make_shared<BAMArrayRead>(idx, std::string(reinterpret_cast<const char*>(rec + 32)), (size_t)clip_lo, (size_t)clip_hi,
+                                              std::move(bases), ChemistryOf(rec, block_size, readGroups));
+    }
+
+    /// Number of ArrayBases DecodeBases will emit for this record (the clipped alignment columns): run arithmetic only.
+    static int64_t CountBases(const uint8_t* rec, int64_t ref_start, int64_t ref_end, int regionStart, int regionEnd)
+    {
+        using namespace detail;
+        const size_t l_read_name = rec[8], n_cigar = U16(rec + 12);
+        const uint8_t* cigar = rec + 32 + l_read_name;
+        const int64_t clip_lo = std::max<int64_t>(ref_start, regionStart), clip_hi = std::min<int64_t>(ref_end, regionEnd);
+        int64_t rp = ref_start, n = 0;
+        for (size_t k = 0; k < n_cigar; ++k) {
+            const uint32_t c = U32(cigar + 4 * k);
+            const int op = c & 15;
+            const int64_t len = c >> 4;
+            if (op == 4 || op == 5 || op > 8) continue;
+            const bool cons_ref = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
+            if (cons_ref) {
+                const int64_t first = std::max(rp, clip_lo), last = std::min(rp + len, clip_hi);
+                if (last > first) n += last - first;
+                rp += len;
+            } else if (rp >= clip_lo && rp <= clip_hi) {
+                n += len;
+            }
+        }
+        return n;
+    }
+
+    /// BAMArrayRead's constructor (src/ArrayRead.cpp:53-99) on the record clipped to the region: one ArrayBase per
+    /// remaining alignment column, handed to `sink` in order.
+    template <typename Sink>
+    static void DecodeBases(const uint8_t* rec, size_t block_size, int64_t ref_start, int64_t ref_end, int regionStart, int regionEnd,
+                            const std::string& filePath, Sink&& sink)
     {
         using namespace detail;
         static const char kSeq[] = "=ACMGRSVTWYHKDBN";
@@ -397,16 +527,10 @@ private:
         const uint8_t* tags = qual + l_seq;
         const uint8_t* end = rec + block_size;
         const bool hasQual = l_seq > 0 && qual[0] != 0xFF;
-        const uint8_t *sq = nullptr, *dq = nullptr, *iq = nullptr, *rg = nullptr;
-        size_t nsq = 0, ndq = 0, niq = 0, nrg = 0;
+        const uint8_t *sq = nullptr, *dq = nullptr, *iq = nullptr;
+        size_t nsq = 0, ndq = 0, niq = 0;
         const bool rich = FindZTag(tags, end, 's', 'q', &sq, &nsq) && FindZTag(tags, end, 'd', 'q', &dq, &ndq) &&
                           FindZTag(tags, end, 'i', 'q', &iq, &niq) && nsq == l_seq && ndq == l_seq && niq == l_seq;
-        std::string chemistry;
-        if (FindZTag(tags, end, 'R', 'G', &rg, &nrg)) {
-            const std::string id(reinterpret_cast<const char*>(rg), nrg);
-            for (const auto& g : readGroups)
-                if (g.first == id) chemistry = g.second;
-        }
         const bool reverse = flag & 0x10;
         auto tagQv = [&](const uint8_t* t, size_t q) -> uint8_t {  // tags are native-oriented; SEQ / QUAL genomic
             const size_t i = reverse ? l_seq - 1 - q : q;
@@ -414,16 +538,14 @@ private:
         };
         // walk the alignment, clipped to [regionStart, regionEnd)
         const int64_t clip_lo = std::max<int64_t>(ref_start, regionStart), clip_hi = std::min<int64_t>(ref_end, regionEnd);
-        std::vector<Data::ArrayBase> bases;
-        bases.reserve((size_t)(clip_hi - clip_lo) + 16);
         int64_t rp = ref_start;
         size_t qp = 0;
         auto emit = [&](char op, char nt, bool has_query, size_t q) {
             const uint8_t qv = has_query ? (hasQual ? qual[q] : 0) : 0;
             if (rich)
-                bases.emplace_back(op, nt, qv, has_query ? tagQv(sq, q) : 0, has_query ? tagQv(dq, q) : 0, has_query ? tagQv(iq, q) : 0);
+                sink(Data::ArrayBase(op, nt, qv, has_query ? tagQv(sq, q) : 0, has_query ? tagQv(dq, q) : 0, has_query ? tagQv(iq, q) : 0));
             else
-                bases.emplace_back(op, nt, qv);  // a record without QUAL: QualQV 0 (ArrayRead.cpp:94-96)
+                sink(Data::ArrayBase(op, nt, qv));  // a record without QUAL: QualQV 0 (ArrayRead.cpp:94-96)
         };
         for (size_t k = 0; k < n_cigar; ++k) {
             const uint32_t c = U32(cigar + 4 * k);
@@ -456,8 +578,6 @@ private:
             }
             if (cons_ref) rp += (int64_t)len;
         }
-        return std::make_shared<BAMArrayRead>(idx, std::string(reinterpret_cast<const char*>(name)), (size_t)clip_lo, (size_t)clip_hi,
-                                              std::move(bases), std::move(chemistry));
     }
 };
 }  // namespace IO

@@ -29,7 +29,10 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <exception>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <map>
 #include <memory>
 #include <numeric>
@@ -190,10 +193,54 @@ class MSAByColumn;
 /// (Majority: the columns whose insertion count can reach that); All = every column, as the reference always does.
 enum class InsertionMode { None, Majority, All };
 
+/// Reads that never become ArrayRead objects: a producer (the BAM front, msq_bam.hpp) that knows every read's
+/// name, reference interval and number of ArrayBases, and writes a read's ArrayBases where it is told to -- the
+/// pinned staging buffer of the device packer.  What BAMArrayRead's constructor computes (src/ArrayRead.cpp:53-99),
+/// without the per-read vectors in between.  fill is called concurrently from several threads.
+struct ReadSource
+{
+    std::vector<std::string> names;
+    std::vector<int32_t> referenceStart, referenceEnd;
+    std::vector<int64_t> numBases;
+    std::function<void(uint64_t read, ArrayBase* dst)> fill;
+};
+
 class MSAByRow  // include/pacbio/data/MSA.h:59-93
 {
 public:
     MSAByRow() = default;
+    MSAByRow(const ReadSource& source, InsertionMode insertions = InsertionMode::None)
+    {
+        const QvThresholds qv;
+        numReads_ = source.names.size();
+        names_ = source.names;
+        struct Relay  // the callback crosses a C boundary: keep the first exception and rethrow it afterwards
+        {
+            const ReadSource* source;
+            std::mutex mutex;
+            std::exception_ptr error;
+            static void Fill(void* user, uint64_t read, msq_array_base* dst)
+            {
+                Relay* self = static_cast<Relay*>(user);
+                try {
+                    self->source->fill(read, reinterpret_cast<ArrayBase*>(dst));
+                } catch (...) {
+                    std::lock_guard<std::mutex> lock(self->mutex);
+                    if (!self->error) self->error = std::current_exception();
+                }
+            }
+        } relay{&source, {}, nullptr};
+        msq_packed_dev* dev = nullptr;
+        const uint32_t packFlags = insertions == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
+        const int rc = msq_pack_reads_device_fill(Msq::Context(), numReads_, source.referenceStart.data(), source.referenceEnd.data(),
+                                                  source.numBases.data(), &Relay::Fill, &relay, packFlags, 0, 0, &dev);
+        if (relay.error) {
+            if (dev) msq_packed_dev_free(Msq::Context(), dev);
+            std::rethrow_exception(relay.error);
+        }
+        Msq::Check(rc);
+        Finish(dev, numReads_ == 0, qv, insertions);
+    }
     MSAByRow(const std::vector<std::shared_ptr<Data::ArrayRead>>& reads, InsertionMode insertions = InsertionMode::None)
     {
         std::vector<const ArrayRead*> p;
@@ -323,6 +370,14 @@ private:
         // the insertion scan needs the genomic order inside each group (plain layout); the pileup takes both
         const uint32_t packFlags = insertionMode == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
         Msq::Check(msq_pack_reads_device(ctx, reads.size(), rs.data(), re.data(), ptr.data(), len.data(), packFlags, 0, 0, &dev));
+        Finish(dev, reads.empty(), qv, insertionMode);
+    }
+
+    // window bounds, pileup and (on request) the insertion histogram of the packed reads now resident in HBM
+    void Finish(msq_packed_dev* dev, bool noReads, const QvThresholds& qv, InsertionMode insertionMode)
+    {
+        struct EmptyTag { bool empty() const { return value; } bool value; } reads{noReads};
+        msq_ctx* ctx = Msq::Context();
         dev_.reset(dev, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // kept for PhaseKeys
         {
             int32_t b0 = 0, e0 = 0;
@@ -698,6 +753,19 @@ class AminoAcidCaller  // include/pacbio/juliet/AminoAcidCaller.h:90-154
 public:
     AminoAcidCaller(const std::vector<std::shared_ptr<Data::ArrayRead>>& reads, const ErrorEstimates& error,
                     const JulietSettings& settings)
+        : msaByRow_(reads)
+        , msaByColumn_(msaByRow_)
+        , error_(error)
+        , targetConfig_(settings.TargetConfigUser)
+        , debug_(settings.Debug)
+        , drmOnly_(settings.DRMOnly)
+        , minimalPerc_(settings.MinimalPerc)
+        , maximalPerc_(settings.MaximalPerc)
+    {
+        CallVariants();
+    }
+    /// The same caller on reads that are decoded straight into the device packer's staging (no ArrayRead objects).
+    AminoAcidCaller(const Data::ReadSource& reads, const ErrorEstimates& error, const JulietSettings& settings)
         : msaByRow_(reads)
         , msaByColumn_(msaByRow_)
         , error_(error)

@@ -277,14 +277,26 @@ static void free_packed_dev(msq_packed_dev* d)
     delete d;
 }
 
-extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
-                                     const msq_array_base* const* bases, const int64_t* n_bases, uint32_t pack_flags,
-                                     int threads, int64_t chunk_bases, msq_packed_dev** out)
+// the records of one read into staging: copied from the caller's array, or written there by the caller's callback
+// (and then OR-ed together from the staging buffer, which is still in cache)
+static uint64_t stage_read(uint64_t* dst, uint64_t r, const msq_array_base* const* bases, const int64_t* n_bases,
+                           msq_fill_read_fn fill, void* user)
+{
+    if (!fill) return copy_or(dst, bases[r], n_bases[r]);
+    fill(user, r, reinterpret_cast<msq_array_base*>(dst));
+    uint64_t acc = 0;
+    for (int64_t i = 0; i < n_bases[r]; ++i) acc |= dst[i];
+    return acc;
+}
+
+static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                  const msq_array_base* const* bases, const int64_t* n_bases, msq_fill_read_fn fill,
+                                  void* user, uint32_t pack_flags, int threads, int64_t chunk_bases, msq_packed_dev** out)
 {
     static_assert(sizeof(msq_array_base) == 8, "msq_array_base is one 8-byte record");
     if (!ctx || !out) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL argument");
     *out = nullptr;
-    if (n_reads && (!ref_start || !ref_end || !bases || !n_bases)) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL array");
+    if (n_reads && (!ref_start || !ref_end || (!bases && !fill) || !n_bases)) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL array");
     if (pack_flags & ~MSQ_PACK_PLAIN) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: unknown pack flag");
     const int plain = (pack_flags & MSQ_PACK_PLAIN) ? 1 : 0;
     MSQ_HIP(hipSetDevice(ctx->device));
@@ -298,7 +310,7 @@ extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32
     }
     base_off[0] = group_off[0] = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
-        if (n_bases[r] < 0 || (n_bases[r] > 0 && !bases[r])) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: bad read %llu", (unsigned long long)r);
+        if (n_bases[r] < 0 || (n_bases[r] > 0 && !fill && !bases[r])) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: bad read %llu", (unsigned long long)r);
         base_off[r + 1] = base_off[r] + (uint64_t)n_bases[r];
         group_off[r + 1] = group_off[r] + (uint64_t)(n_bases[r] + 31) / 32;
         longest = std::max(longest, n_bases[r]);
@@ -371,7 +383,7 @@ extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32
         uint64_t any = 0;
         const unsigned workers = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_thr, cb >> 17));  // >= 1 MB each
         if (workers == 1) {
-            for (uint64_t r = r0; r < r1; ++r) any |= copy_or(hs + (base_off[r] - base_off[r0]), bases[r], n_bases[r]);
+            for (uint64_t r = r0; r < r1; ++r) any |= stage_read(hs + (base_off[r] - base_off[r0]), r, bases, n_bases, fill, user);
         } else {
             std::vector<uint64_t> ors(workers, 0);
             std::vector<std::thread> pool;
@@ -382,7 +394,7 @@ extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32
                 const uint64_t rb = t + 1 == workers ? r1 : std::lower_bound(base_off.begin() + r0, base_off.begin() + r1, hi_b) - base_off.begin();
                 pool.emplace_back([&, t, ra, rb] {
                     uint64_t acc = 0;
-                    for (uint64_t r = ra; r < rb; ++r) acc |= copy_or(hs + (base_off[r] - base_off[r0]), bases[r], n_bases[r]);
+                    for (uint64_t r = ra; r < rb; ++r) acc |= stage_read(hs + (base_off[r] - base_off[r0]), r, bases, n_bases, fill, user);
                     ors[t] = acc;
                 });
             }
@@ -444,4 +456,20 @@ extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32
     v.reserved = 0;
     *out = d;
     return MSQ_OK;
+}
+
+extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                     const msq_array_base* const* bases, const int64_t* n_bases, uint32_t pack_flags,
+                                     int threads, int64_t chunk_bases, msq_packed_dev** out)
+{
+    if (n_reads && !bases) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL array");
+    return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, bases, n_bases, nullptr, nullptr, pack_flags, threads, chunk_bases, out);
+}
+
+extern "C" int msq_pack_reads_device_fill(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                          const int64_t* n_bases, msq_fill_read_fn fill, void* user, uint32_t pack_flags,
+                                          int threads, int64_t chunk_bases, msq_packed_dev** out)
+{
+    if (!fill) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device_fill: fill is NULL");
+    return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, nullptr, n_bases, fill, user, pack_flags, threads, chunk_bases, out);
 }

@@ -17,16 +17,48 @@ int main(int argc, char** argv)
         std::fprintf(stderr, "usage: bam_test file.bam regionStart regionEnd [--call] [--time] [--threads N]\n");
         return 2;
     }
-    bool call = false, time_only = false;
+    bool call = false, time_only = false, direct = false;
     unsigned threads = 4;
     for (int i = 4; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--call")) call = true;
+        if (!std::strcmp(argv[i], "--direct")) direct = true;
         if (!std::strcmp(argv[i], "--time")) time_only = true;
         if (!std::strcmp(argv[i], "--top-pad") && i + 1 < argc) mallopt(M_TOP_PAD, std::atoi(argv[++i]) << 20);  // experiment: arena growth step, MB
         if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)std::atoi(argv[++i]);
     }
     try {
         IO::BamTimings tm;
+        if (direct) {  // BAM records decoded straight into the device packer's staging: no ArrayRead objects
+            const Juliet::ErrorEstimates error("S/P2-C2");
+            Juliet::JulietSettings s;
+            double call_s[2] = {0, 0}, load_s[2] = {0, 0};
+            for (int rep = 0; rep < (time_only ? 2 : 1); ++rep) {
+                const auto l0 = std::chrono::steady_clock::now();
+                std::vector<std::string> chems;
+                const Data::ReadSource source = IO::BamUtils::BamToReadSource(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), threads, &tm, &chems);
+                const auto c0 = std::chrono::steady_clock::now();
+                Juliet::AminoAcidCaller aac(source, error, s);
+                const auto c1 = std::chrono::steady_clock::now();
+                load_s[rep] = std::chrono::duration<double>(c0 - l0).count();
+                call_s[rep] = std::chrono::duration<double>(c1 - c0).count();
+                if (!time_only) {
+                    std::printf("READS bam\n");
+                    for (size_t r = 0; r < source.names.size(); ++r)
+                        std::printf("SRC %d %d %lld NAME %s\n", source.referenceStart[r], source.referenceEnd[r], (long long)source.numBases[r],
+                                    source.names[r].c_str());
+                    for (const auto& c : chems) std::printf("CHEMS %s\n", c.empty() ? "." : c.c_str());
+                    Dump("bam", aac);
+                }
+            }
+            if (time_only) {
+                size_t bases = 0;
+                std::printf("TIMING threads %u file_bytes %zu bam_bytes %zu records %zu kept %zu bases %zu read_s %.4f inflate_s %.4f index_s %.4f parse_s %.4f "
+                            "call_first_s %.4f call_s %.4f load_s %.4f\n",
+                            threads, tm.file_bytes, tm.bam_bytes, tm.records, tm.kept, bases, tm.read, tm.inflate, tm.index, tm.parse, call_s[0], call_s[1],
+                            load_s[1]);
+            }
+            return 0;
+        }
         const auto reads = IO::BamUtils::BamToArrayReads(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), threads, &tm);
         if (time_only) {  // decode rate of the front on its own (host only)
             size_t bases = 0;

@@ -271,3 +271,36 @@ def test_bam_to_counts_matches_oracle(tmp_path, ref, rich):
     for i in range(m.W):
         assert got_cod.get(i, {}) == {pymodel.CODONS[k]: int(v) for k, v in enumerate(cod[i]) if v}, i
     assert sum(len(v) for v in got_cod.values()) > 500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rich,clean,region", [(False, True, (31, 391)), (True, True, (0, INT_MAX)), (True, False, (100, 300))])
+def test_direct_decode_equals_array_read_path(tmp_path, ref, rich, clean, region):
+    """BamToReadSource + AminoAcidCaller(ReadSource) -- records decoded straight into the device packer's staging
+    buffer -- against BamToArrayReads + AminoAcidCaller(reads): the same names, intervals and base counts, and an
+    identical dump (counts, codons, variants, p-values), also for records with soft clips, pads, N ops, absent
+    QUAL and mixed rich tags (`clean=False`: those only through the read tables, the caller refuses 'N' cigars)."""
+    rng = np.random.default_rng(31 + rich + 2 * clean)
+    recs = make_records(rng, ref, 1200, clean=clean, rich=rich)
+    path = str(tmp_path / "d.bam")
+    write_bam(path, recs, len(ref), block=30000)
+    want = expected_reads(recs, *region)
+    if clean:
+        rc_a, reads_a, rest_a = run_bam_test(path, *region, "--call")
+        rc_d, _, rest_d = run_bam_test(path, *region, "--call", "--direct", "--threads", "7")
+        assert rc_a == 0 and rc_d == 0
+        src = [l.split(" ") for l in rest_d if l.startswith("SRC ")]
+        assert [(int(t[1]), int(t[2]), int(t[3]), t[5]) for t in src] == [(w[0], w[1], len(w[2]), w[5]) for w in want]
+        body = lambda rest: [l for l in rest if l.split(" ")[0] in ("CASE", "BEGIN", "NUC", "CODON", "NTESTS", "VAR", "MSA", "PERF")]
+        assert body(rest_d) == body(rest_a) and len(body(rest_a)) > 400
+        chems = [l.split(" ")[1] for l in rest_d if l.startswith("CHEMS ")]
+        assert chems == [CHEM["abcd1234"]]
+    else:
+        rc_d, _, rest_d = run_bam_test(path, *region, "--call", "--direct")
+        src = [l.split(" ") for l in rest_d if l.startswith("SRC ")]
+        if rc_d == 0:  # no 'N' / 'M' cigar survived the region
+            assert [(int(t[1]), int(t[2]), int(t[3]), t[5]) for t in src] == [(w[0], w[1], len(w[2]), w[5]) for w in want]
+        else:  # the caller's own refusal, as through the ArrayRead path (src/MSA.cpp:182)
+            assert any(l.startswith("ERR Unexpected cigar") for l in rest_d)
+            rc_a, _, rest_a = run_bam_test(path, *region, "--call")
+            assert rc_a == 1 and [l for l in rest_a if l.startswith("ERR")] == [l for l in rest_d if l.startswith("ERR")]
