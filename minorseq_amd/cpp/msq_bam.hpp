@@ -307,21 +307,37 @@ struct BamUtils
         const auto t3 = Clock::now();
         Data::ReadSource source;
         const size_t n = loaded->kept.size();
-        source.names.reserve(n);
-        source.referenceStart.reserve(n);
-        source.referenceEnd.reserve(n);
-        source.numBases.reserve(n);
-        for (const Kept& k : loaded->kept) {
-            const uint8_t* rec = &loaded->data[k.off];
-            source.names.emplace_back(reinterpret_cast<const char*>(rec + 32));
-            source.referenceStart.push_back((int32_t)std::max<int64_t>(k.ref_start, regionStart));
-            source.referenceEnd.push_back((int32_t)std::min<int64_t>(k.ref_end, regionEnd));
-            source.numBases.push_back(CountBases(rec, k.ref_start, k.ref_end, regionStart, regionEnd));
-            if (chemistries) {
-                const std::string chem = ChemistryOf(rec, k.block_size, loaded->readGroups);
-                if (std::find(chemistries->begin(), chemistries->end(), chem) == chemistries->end()) chemistries->push_back(chem);
+        source.names.resize(n);
+        source.referenceStart.resize(n);
+        source.referenceEnd.resize(n);
+        source.numBases.resize(n);
+        const unsigned workers = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, n / 4096 + 1));
+        std::vector<std::vector<std::string>> chemsOf(workers);  // distinct strings per worker, in order of appearance
+        auto tables = [&](unsigned w) {
+            for (size_t r = n * w / workers; r < n * (w + 1) / workers; ++r) {
+                const Kept& k = loaded->kept[r];
+                const uint8_t* rec = &loaded->data[k.off];
+                source.names[r] = reinterpret_cast<const char*>(rec + 32);
+                source.referenceStart[r] = (int32_t)std::max<int64_t>(k.ref_start, regionStart);
+                source.referenceEnd[r] = (int32_t)std::min<int64_t>(k.ref_end, regionEnd);
+                source.numBases[r] = CountBases(rec, k.ref_start, k.ref_end, regionStart, regionEnd);
+                if (chemistries) {
+                    std::string chem = ChemistryOf(rec, k.block_size, loaded->readGroups);
+                    if (std::find(chemsOf[w].begin(), chemsOf[w].end(), chem) == chemsOf[w].end()) chemsOf[w].push_back(std::move(chem));
+                }
             }
+        };
+        if (workers == 1) {
+            tables(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned w = 0; w < workers; ++w) pool.emplace_back(tables, w);
+            for (auto& th : pool) th.join();
         }
+        if (chemistries)
+            for (const auto& part : chemsOf)  // workers own consecutive record ranges: concatenation keeps the order
+                for (const auto& chem : part)
+                    if (std::find(chemistries->begin(), chemistries->end(), chem) == chemistries->end()) chemistries->push_back(chem);
         source.fill = [loaded, regionStart, regionEnd, filePath](uint64_t read, Data::ArrayBase* dst) {
             const Kept& k = loaded->kept[read];
             DecodeBases(&loaded->data[k.off], k.block_size, k.ref_start, k.ref_end, regionStart, regionEnd, filePath,
