@@ -171,7 +171,7 @@ def main():
         abi.check(L.msq_window_bounds_device(ctx.h, dr.view, bounds.data_ptr()))
         sharding.allreduce_bounds_device(bounds)  # N > 1: one 2-int MAX
         counts.zero_()
-        abi.check(L.msq_pileup_device_window(ctx.h, dr.view, thr, bounds.data_ptr(), W, nuc.data_ptr(), codon.data_ptr()))
+        abi.check(L.msq_pileup_device_window(ctx.h, dr.view, thr, bounds.data_ptr(), b0, W, nuc.data_ptr(), codon.data_ptr()))
         sharding.allreduce_counts(counts)
         abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
                                    plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))

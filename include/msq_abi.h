@@ -177,12 +177,15 @@ int msq_window_bounds_device(msq_ctx* ctx, const msq_packed_reads* d_reads, int3
 int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
                int32_t W, uint32_t* d_nuc, uint32_t* d_codon, int mode);
 /* msq_pileup whose window comes from device memory, as msq_window_bounds_device (and a MAX all-reduce) left it:
- * window = [-d_bounds[0], d_bounds[1]).  The count matrices hold W_max columns; a wider window raises the
- * deferred MSQ_ERR_WINDOW, columns beyond the window stay untouched.  No host synchronisation anywhere: bounds
- * -> pileup -> msq_call_cells run back to back on the stream.  Streaming kernel only (reads without
- * MSQ_READS_HAS_EXOTIC); otherwise MSQ_ERR_ARG.  Same reference lines as msq_pileup. */
+ * window = [-d_bounds[0], d_bounds[1]).  The caller sized its count matrices (W_max columns) and its plan for a
+ * window that starts at begin0: a window with another origin, or wider than W_max, raises the deferred
+ * MSQ_ERR_WINDOW (so msq_call_cells never reads counts laid out for another window unnoticed); a narrower one
+ * leaves the columns beyond it untouched.  No host synchronisation anywhere: bounds -> pileup -> msq_call_cells
+ * run back to back on the stream.  Streaming kernel only (reads without MSQ_READS_HAS_EXOTIC); otherwise
+ * MSQ_ERR_ARG.  Same reference lines as msq_pileup. */
 int msq_pileup_device_window(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,
-                             const int32_t* d_bounds, int32_t W_max, uint32_t* d_nuc, uint32_t* d_codon);
+                             const int32_t* d_bounds, int32_t begin0, int32_t W_max, uint32_t* d_nuc,
+                             uint32_t* d_codon);
 /* Deferred device-side error of the pileups enqueued since the last check (MSQ_ERR_BASE / MSQ_ERR_WINDOW).
  * Synchronises. */
 int msq_pileup_check(msq_ctx* ctx);

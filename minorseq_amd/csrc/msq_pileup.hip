@@ -204,7 +204,8 @@ extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const m
 }
 
 extern "C" int msq_pileup_device_window(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,
-                                        const int32_t* d_bounds, int32_t W_max, uint32_t* d_nuc, uint32_t* d_codon)
+                                        const int32_t* d_bounds, int32_t begin0, int32_t W_max, uint32_t* d_nuc,
+                                        uint32_t* d_codon)
 {
     if (!ctx || !d_reads || !thr || !d_bounds) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: NULL argument");
     if (W_max < 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: negative capacity %d", W_max);
@@ -220,7 +221,7 @@ extern "C" int msq_pileup_device_window(msq_ctx* ctx, const msq_packed_reads* d_
     }
     MSQ_HIP(hipSetDevice(ctx->device));
     bool handled = false;
-    int rc = msq_pileup_stream_launch(ctx, *d_reads, *thr, 0, W_max, d_bounds, d_nuc, d_codon, &handled);
+    int rc = msq_pileup_stream_launch(ctx, *d_reads, *thr, begin0, W_max, d_bounds, d_nuc, d_codon, &handled);
     if (rc != MSQ_OK) return rc;
     if (!handled) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: needs the streaming kernel (flags=%u)", d_reads->flags);
     return MSQ_OK;

@@ -393,7 +393,8 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     if (a.d_bounds) {  // the window as the bounds kernel (and the all-reduce over the shards) left it in HBM
         win_begin0 = -a.d_bounds[0];
         const int w = a.d_bounds[1] - win_begin0;
-        if (w < 0 || w > W) my_err |= DEVERR_WINDOW;  // wider than the count matrices
+        // not the window the caller sized its matrices and plan for: another origin, or wider than the matrices
+        if (win_begin0 != a.win_begin0 || w < 0 || w > W) my_err |= DEVERR_WINDOW;
         W = w < 0 ? 0 : w < W ? w : W;
     }
     const int slab0 = a.slab0, wbase = slab0 >> 5;            // window word of the slab's word 0

@@ -218,11 +218,12 @@ def window_bounds_device(ctx, dr, out=None):
     return out
 
 
-def pileup_device_window(ctx, dr, thr, bounds, W_max, nuc=None, codon=None, check=True):
-    """msq_pileup_device_window: the window is read from `bounds` (device), the matrices hold W_max columns."""
+def pileup_device_window(ctx, dr, thr, bounds, begin0, W_max, nuc=None, codon=None, check=True):
+    """msq_pileup_device_window: the window is read from `bounds` (device); the caller expects it to start at
+    begin0 and its matrices hold W_max columns."""
     if nuc is None:
         nuc, codon = alloc_counts(ctx, W_max)
-    abi.check(abi.lib().msq_pileup_device_window(ctx.h, dr.view, thr, bounds.data_ptr(), W_max, nuc.data_ptr(), codon.data_ptr()))
+    abi.check(abi.lib().msq_pileup_device_window(ctx.h, dr.view, thr, bounds.data_ptr(), begin0, W_max, nuc.data_ptr(), codon.data_ptr()))
     if check:
         abi.check(abi.lib().msq_pileup_check(ctx.h))
     return nuc, codon

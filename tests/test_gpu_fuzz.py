@@ -45,7 +45,7 @@ def test_fuzz(ctx, seed):
             assert (codon.cpu().numpy()[:m.W * 64].reshape(-1, 64) == m.codon_counts()).all(), (plain, mode)
         if not (dr.flags & abi.MSQ_READS_HAS_EXOTIC):  # the window left in HBM, matrices wider than the window
             bounds = device.window_bounds_device(ctx, dr)
-            nuc, codon = device.pileup_device_window(ctx, dr, q, bounds, m.W + seed % 5)
+            nuc, codon = device.pileup_device_window(ctx, dr, q, bounds, b0, m.W + seed % 5)
             assert bounds.tolist() == [-b0, e0]
             assert (nuc.cpu().numpy()[:m.W * 6].reshape(-1, 6) == m.nuc_counts()).all(), plain
             assert (codon.cpu().numpy()[:m.W * 64].reshape(-1, 64) == m.codon_counts()).all(), plain

@@ -234,16 +234,20 @@ def test_device_resident_window(ctx, name):
     W = e - b
     if dr.flags & abi.MSQ_READS_HAS_EXOTIC:  # the streaming kernel does not take these: a clear refusal
         with pytest.raises(abi.MsqError) as err:
-            device.pileup_device_window(ctx, dr, q, bounds, W)
+            device.pileup_device_window(ctx, dr, q, bounds, b, W)
         assert err.value.code == abi.MSQ_ERR_ARG
         return
     want_nuc, want_codon = device.pileup(ctx, dr, q, b, W)
     for W_max in (W, W + 1, W + 77):
-        nuc, codon = device.pileup_device_window(ctx, dr, q, bounds, W_max)
+        nuc, codon = device.pileup_device_window(ctx, dr, q, bounds, b, W_max)
         nuc, codon = nuc.cpu().numpy().reshape(-1, 6), codon.cpu().numpy().reshape(-1, 64)
         assert (nuc[:W] == want_nuc.cpu().numpy().reshape(-1, 6)[:W]).all() and not nuc[W:].any()
         assert (codon[:W] == want_codon.cpu().numpy().reshape(-1, 64)[:W]).all() and not codon[W:].any()
     if W > 3:
         with pytest.raises(abi.MsqError) as err:
-            device.pileup_device_window(ctx, dr, q, bounds, W - 1)
+            device.pileup_device_window(ctx, dr, q, bounds, b, W - 1)
+        assert err.value.code == abi.MSQ_ERR_WINDOW
+    for wrong in (b - 1, b + 1):  # the plan and the matrices were made for another origin
+        with pytest.raises(abi.MsqError) as err:
+            device.pileup_device_window(ctx, dr, q, bounds, wrong, W + 4)
         assert err.value.code == abi.MSQ_ERR_WINDOW
