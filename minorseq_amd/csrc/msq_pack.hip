@@ -319,7 +319,7 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
     uint64_t cap = chunk_bases > 0 ? (uint64_t)chunk_bases : (uint64_t)32 << 20;  // records per chunk (256 MB)
     cap = std::max<uint64_t>(std::min(cap, total_bases), (uint64_t)longest);
     const size_t stage_bytes = std::max<size_t>(cap * 8, 64);
-    unsigned n_thr = threads > 0 ? (unsigned)threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const unsigned n_thr = threads > 0 ? std::min(64u, (unsigned)threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
 
     // staging: two pinned host buffers (kept by the context), one device buffer + the error words in the scratch
     if (ctx->h_stage_bytes < stage_bytes) {
@@ -385,21 +385,33 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
         if (workers == 1) {
             for (uint64_t r = r0; r < r1; ++r) any |= stage_read(hs + (base_off[r] - base_off[r0]), r, bases, n_bases, fill, user);
         } else {
-            std::vector<uint64_t> ors(workers, 0);
+            uint64_t ors[64] = {0};
             std::vector<std::thread> pool;
-            for (unsigned t = 0; t < workers; ++t) {
-                // reads whose first base falls into this worker's share of the chunk's bases
-                const uint64_t lo_b = base_off[r0] + cb * t / workers, hi_b = base_off[r0] + cb * (t + 1) / workers;
-                const uint64_t ra = std::lower_bound(base_off.begin() + r0, base_off.begin() + r1, lo_b) - base_off.begin();
-                const uint64_t rb = t + 1 == workers ? r1 : std::lower_bound(base_off.begin() + r0, base_off.begin() + r1, hi_b) - base_off.begin();
-                pool.emplace_back([&, t, ra, rb] {
-                    uint64_t acc = 0;
-                    for (uint64_t r = ra; r < rb; ++r) acc |= stage_read(hs + (base_off[r] - base_off[r0]), r, bases, n_bases, fill, user);
-                    ors[t] = acc;
-                });
+            bool spawned = true;
+            try {  // no C++ exception may leave through the C ABI, and no joinable thread may be destroyed
+                pool.reserve(workers);
+                for (unsigned t = 0; t < workers; ++t) {
+                    // reads whose first base falls into this worker's share of the chunk's bases
+                    const uint64_t lo_b = base_off[r0] + cb * t / workers, hi_b = base_off[r0] + cb * (t + 1) / workers;
+                    const uint64_t ra = std::lower_bound(base_off.begin() + r0, base_off.begin() + r1, lo_b) - base_off.begin();
+                    const uint64_t rb = t + 1 == workers ? r1 : std::lower_bound(base_off.begin() + r0, base_off.begin() + r1, hi_b) - base_off.begin();
+                    pool.emplace_back([&, t, ra, rb] {
+                        uint64_t acc = 0;
+                        for (uint64_t r = ra; r < rb; ++r) acc |= stage_read(hs + (base_off[r] - base_off[r0]), r, bases, n_bases, fill, user);
+                        ors[t] = acc;
+                    });
+                }
+            } catch (...) {
+                spawned = false;
             }
             for (auto& th : pool) th.join();
-            for (uint64_t o : ors) any |= o;
+            if (!spawned) {
+                (void)hipStreamSynchronize(ctx->stream);
+                if (d_base_off) (void)hipFree(d_base_off);
+                free_packed_dev(d);
+                return msq_fail(MSQ_ERR_NOMEM, "msq_pack_reads_device: cannot start %u staging threads", workers);
+            }
+            for (unsigned t = 0; t < workers; ++t) any |= ors[t];
         }
         // QV planes appear with the first chunk that carries the QV; every base before it lacked it -> 255
         const bool want[4] = {((any >> 16) & 0xff) != 0, ((any >> 24) & 0xff) != 0, ((any >> 24) & 0xff) != 0, ((any >> 24) & 0xff) != 0};
