@@ -186,6 +186,23 @@ int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thres
 int msq_pileup_device_window(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,
                              const int32_t* d_bounds, int32_t begin0, int32_t W_max, uint32_t* d_nuc,
                              uint32_t* d_codon);
+/* Column-slab partition, the HBM layout for windows wider than one slab of the streaming kernel (4096 columns:
+ * the 9.7 kb HIV genome, 20 kb amplicons).  msq_pileup takes one launch per slab and, over the whole read set,
+ * streams every read once per slab; the partition holds per slab a packed read set of its own with, of every
+ * read, only the 32-base groups that reach into the slab's columns (and the two columns to its right, for the
+ * slab's last codons).  Sub-reads are ordinary packed reads (group-aligned copies; ReferenceStart = the column of
+ * the first copied group), so the counts are those of msq_pileup, while every launch streams only its slab's
+ * share.  A pack-time step (one scan of the bit planes, one gather); d_reads stays valid and untouched.
+ * Synchronises.  Same reference lines as msq_pileup. */
+typedef struct msq_partition msq_partition;
+int msq_reads_partition(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t win_begin0, int32_t W,
+                        msq_partition** out);
+int msq_partition_slabs(const msq_partition* p);
+const msq_packed_reads* msq_partition_view(const msq_partition* p, int slab); /* device pointers inside */
+int msq_partition_free(msq_ctx* ctx, msq_partition* p);
+/* msq_pileup over the partition's window: slab after slab, each over its own read set.  Async. */
+int msq_pileup_partition(msq_ctx* ctx, const msq_partition* p, const msq_qv_thresholds* thr, uint32_t* d_nuc,
+                         uint32_t* d_codon);
 /* Deferred device-side error of the pileups enqueued since the last check (MSQ_ERR_BASE / MSQ_ERR_WINDOW).
  * Synchronises. */
 int msq_pileup_check(msq_ctx* ctx);

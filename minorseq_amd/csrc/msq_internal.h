@@ -37,6 +37,13 @@ struct msq_ctx {
     int ev_used = 0;
 };
 
+// Packed reads resident in HBM and owned by the library: the eight arrays of msq_packed_reads (ref_start, ref_end,
+// group_off, bop, qual, delqv, subqv, insqv; absent planes NULL) and the view over them.
+struct msq_packed_dev {
+    void* ptrs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    msq_packed_reads view;
+};
+
 // Record the begin / end event of the next timing slot (no-ops when timing is off or the slots are used up).
 void msq_timing_mark_begin(msq_ctx* ctx);
 void msq_timing_mark_end(msq_ctx* ctx);

@@ -16,10 +16,6 @@ struct msq_packed_host {
     msq_packed_reads view;
 };
 
-struct msq_packed_dev {
-    void* ptrs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    msq_packed_reads view;
-};
 
 // Per-base translation of (ArrayBase::Cigar, ArrayBase::Nucleotide) as MSAByRow::AddRead switches on
 // them (src/MSA.cpp:158-184).  Returns false on an unknown cigar char ("Unexpected cigar", :182).

@@ -852,17 +852,29 @@ struct PhaseRequest {
     uint16_t* d_keys;
 };
 
+// The column slabs of a W-column window: windows wider than 128 words (4096 columns) are cut into equal slabs of
+// <= 128 words.  Slab s covers window columns [s * Gslab * 32, min(W, (s + 1) * Gslab * 32)).
+void msq_slab_layout(int32_t W, int* n_slabs, int* Gslab)
+{
+    const int Gtot = (W + 31) / 32;
+    *n_slabs = Gtot ? (Gtot + 127) / 128 : 0;
+    *Gslab = *n_slabs ? (Gtot + *n_slabs - 1) / *n_slabs : 0;
+}
+
 static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
-                         const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon, const PhaseRequest* phase, bool* handled)
+                         const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon, const PhaseRequest* phase, bool* handled,
+                         int only_slab = -1)
 {
     *handled = false;
     if (R.flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
-    if (R.n_groups == 0) return MSQ_OK;
-    // column slabs: windows wider than 128 words (4096 columns) are cut into equal slabs of <= 128 words and the
-    // reads are streamed once per slab (a launch places only the bases that fall into its slab and margins)
+    if (R.n_groups == 0) {
+        *handled = only_slab >= 0;  // a slab's read set may well be empty
+        return MSQ_OK;
+    }
+    // the reads are streamed once per slab (a launch places only the bases that fall into its slab and margins)
     const int Gtot = (W + 31) / 32;
-    const int n_slabs = (Gtot + 127) / 128;
-    const int Gslab = (Gtot + n_slabs - 1) / n_slabs;
+    int n_slabs = 0, Gslab = 0;
+    msq_slab_layout(W, &n_slabs, &Gslab);
 
     // the QV planes that can mask a base (threshold set and plane present; ArrayRead.inl:67-87), compacted
     StreamArgs a;
@@ -898,7 +910,8 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     a.ph_n = a.ph_total = 0;
     a.ph_keys = nullptr;
     if (!phase) msq_timing_mark_begin(ctx);
-    for (int slab = 0; slab < n_slabs; ++slab) {
+    if (only_slab >= n_slabs) return msq_fail(MSQ_ERR_ARG, "msq_pileup_slab: slab %d of %d", only_slab, n_slabs);
+    for (int slab = only_slab >= 0 ? only_slab : 0; slab < (only_slab >= 0 ? only_slab + 1 : n_slabs); ++slab) {
         const int G = std::min(Gslab, Gtot - slab * Gslab);
         const int passes = phase ? 1 : G <= 64 ? 1 : 2;
         const int RD = G + 4;
@@ -941,7 +954,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
             a.ph_total = phase->n_pos;
             a.ph_keys = phase->d_keys;
         }
-        const bool last_slab = slab == n_slabs - 1;
+        const bool last_slab = slab == (only_slab >= 0 ? only_slab : n_slabs - 1);
         for (uint64_t lo = 0; lo < R.n_reads; lo += reads_per_launch) {
             const uint64_t hi = std::min<uint64_t>(R.n_reads, lo + reads_per_launch);
             const uint64_t n_batches = (hi - lo + kRows - 1) / kRows;
@@ -985,6 +998,13 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
                              int32_t W, const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
 {
     return stream_launch(ctx, R, thr, win_begin0, W, d_bounds, d_nuc, d_codon, nullptr, handled);
+}
+
+// one column slab only (msq_pileup_slab): the caller's read set need hold no bases outside that slab and its margins
+int msq_pileup_stream_slab_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
+                                  int32_t W, int slab, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
+{
+    return stream_launch(ctx, R, thr, win_begin0, W, nullptr, d_nuc, d_codon, nullptr, handled, slab);
 }
 
 int msq_phase_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,

@@ -229,6 +229,54 @@ def pileup_device_window(ctx, dr, thr, bounds, begin0, W_max, nuc=None, codon=No
     return nuc, codon
 
 
+class Partition:
+    """msq_reads_partition: per column slab a packed read set of its own (library-owned HBM)."""
+
+    def __init__(self, ctx, dr, win_begin0, W):
+        self.ctx, self.win_begin0, self.W = ctx, win_begin0, W
+        h = C.c_void_p()
+        abi.check(abi.lib().msq_reads_partition(ctx.h, dr.view, win_begin0, W, C.byref(h)))
+        self._h = h
+        self.n_slabs = abi.lib().msq_partition_slabs(h)
+
+    def view(self, slab):
+        return abi.lib().msq_partition_view(self._h, slab).contents
+
+    def n_groups(self):
+        return [int(self.view(s).n_groups) for s in range(self.n_slabs)]
+
+    def tables(self, slab):
+        """(ref_start, ref_end, group_off) of a slab's sub-reads, copied back."""
+        v = self.view(slab)
+        n = int(v.n_reads)
+        out = []
+        for addr, dtype, count in ((v.ref_start, np.int32, n), (v.ref_end, np.int32, n), (v.group_off, np.uint64, n + 1)):
+            a = np.zeros(count, dtype=dtype)
+            if count and addr:
+                abi.check(abi.lib().msq_memcpy_d2h(self.ctx.h, abi.ptr(a), addr, a.nbytes))
+            out.append(a)
+        return out
+
+    def pileup(self, thr, nuc=None, codon=None, check=True):
+        if nuc is None:
+            nuc, codon = alloc_counts(self.ctx, self.W)
+        abi.check(abi.lib().msq_pileup_partition(self.ctx.h, self._h, thr, nuc.data_ptr(), codon.data_ptr()))
+        if check:
+            abi.check(abi.lib().msq_pileup_check(self.ctx.h))
+        return nuc, codon
+
+    def close(self):
+        if self._h:
+            abi.lib().msq_partition_free(self.ctx.h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def alloc_counts(ctx, W):
     dev = torch.device("cuda", ctx.device)
     return (torch.zeros(max(W, 1) * 6, dtype=torch.int32, device=dev),
