@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--host-bounds", action="store_true", help="bring the window bounds back to the host every step "
                     "(msq_window_bounds + msq_pileup) instead of leaving them in HBM (msq_window_bounds_device + "
                     "msq_pileup_device_window, the default)")
+    ap.add_argument("--no-partition", action="store_true", help="windows wider than 4096 columns: run every slab launch "
+                    "over the whole read set instead of over the column-slab partition built at set-up")
+    ap.add_argument("--slab-columns", type=int, default=0, help="widest column slab of the partition (multiple of 32, "
+                    "<= 4096); narrower than the window: partition even a window that fits one slab")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the RCCL process group and issue "
                     "the step's collectives even with one rank")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the CPU baseline sample (0 = skip)")
@@ -176,7 +180,23 @@ def main():
         abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
                                    plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))
 
-    step = step_host_bounds if (a.host_bounds or a.mode == "simple") else step_device_bounds
+    # windows wider than one slab of the streaming kernel: the reads are laid out per column slab at set-up (pack
+    # time, untimed like the packing itself), so that every slab launch streams only its share of the reads
+    part = None
+    if (W > 4096 or 0 < a.slab_columns < W) and not a.no_partition and a.mode != "simple":
+        part = device.Partition(ctx, dr, b0, W, a.slab_columns)
+
+    def step_partition():
+        abi.check(L.msq_window_bounds_device(ctx.h, dr.view, bounds.data_ptr()))
+        sharding.allreduce_bounds_device(bounds)
+        counts.zero_()
+        abi.check(L.msq_pileup_partition(ctx.h, part._h, thr, nuc.data_ptr(), codon.data_ptr()))
+        sharding.allreduce_counts(counts)
+        abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
+                                   plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))
+
+    step = step_partition if part else step_host_bounds if (a.host_bounds or a.mode == "simple") else step_device_bounds
+    launches_per_step = part.n_slabs if part else 1  # timing slots: one per pileup call that reaches the kernel
 
     def barrier():
         if world > 1 or a.force_dist:
@@ -187,7 +207,7 @@ def main():
         step()
     abi.check(L.msq_pileup_check(ctx.h))
     abi.check(L.msq_call_check(ctx.h))
-    abi.check(L.msq_timing_enable(ctx.h, a.steps))
+    abi.check(L.msq_timing_enable(ctx.h, a.steps * launches_per_step))
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -196,13 +216,14 @@ def main():
     dt = time.perf_counter() - t0
     abi.check(L.msq_pileup_check(ctx.h))
     abi.check(L.msq_call_check(ctx.h))
-    if step is step_device_bounds and bounds.tolist() != [-b0, e0]:
+    if step is not step_host_bounds and bounds.tolist() != [-b0, e0]:
         raise SystemExit("device-resident window bounds %s differ from the set-up window [%d, %d)" % (bounds.tolist(), b0, e0))
-    ms = (C.c_float * a.steps)()
+    n_slots = a.steps * launches_per_step
+    ms = (C.c_float * n_slots)()
     n_ms = C.c_int32(0)
-    abi.check(L.msq_timing_read(ctx.h, ms, a.steps, C.byref(n_ms)))
+    abi.check(L.msq_timing_read(ctx.h, ms, n_slots, C.byref(n_ms)))
     abi.check(L.msq_timing_enable(ctx.h, 0))
-    kernel_ms = sum(ms[:n_ms.value]) / max(1, n_ms.value)
+    kernel_ms = sum(ms[:n_ms.value]) / max(1, a.steps)  # per step: the slab launches of a partition added up
 
     pcie = None
     if a.h2d_steps > 0 and world == 1:  # the boundary handing over host buffers: packed reads cross PCIe every step
@@ -243,7 +264,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %d reads/GPU x %d columns (HXB2 pol, 1%% minors), QUALQV=%s" % (
                 wl.name, reads, W, "unset" if a.qualqv < 0 else a.qualqv), "mode": a.mode,
-                "window_bounds": "device-resident" if step is step_device_bounds else "host round trip per step",
+                "window_bounds": "host round trip per step" if step is step_host_bounds else "device-resident",
+                "column_slabs": (part.n_slabs if part else (((W + 31) // 32) + 127) // 128),
+                "read_layout": "column-slab partition (built at set-up)" if part else "one read set",
                 "bases_per_gpu": int(n_bases), "codon_positions": plan.P, "number_of_tests": int(plan.n_tests.item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kernel_name, wl.name, reads, a.qualqv),

@@ -193,10 +193,12 @@ int msq_pileup_device_window(msq_ctx* ctx, const msq_packed_reads* d_reads, cons
  * slab's last codons).  Sub-reads are ordinary packed reads (group-aligned copies; ReferenceStart = the column of
  * the first copied group), so the counts are those of msq_pileup, while every launch streams only its slab's
  * share.  A pack-time step (one scan of the bit planes, one gather); d_reads stays valid and untouched.
+ * max_slab_columns: the widest slab wanted, a multiple of 32 up to 4096 (<= 0: 4096, the fastest measured:
+ * every sub-read costs the kernel a read's worth of bookkeeping, so fewer, wider slabs win).
  * Synchronises.  Same reference lines as msq_pileup. */
 typedef struct msq_partition msq_partition;
 int msq_reads_partition(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t win_begin0, int32_t W,
-                        msq_partition** out);
+                        int32_t max_slab_columns, msq_partition** out);
 int msq_partition_slabs(const msq_partition* p);
 const msq_packed_reads* msq_partition_view(const msq_partition* p, int slab); /* device pointers inside */
 int msq_partition_free(msq_ctx* ctx, msq_partition* p);

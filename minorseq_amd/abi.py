@@ -102,7 +102,7 @@ _SIGNATURES = {
     "msq_window_bounds": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "msq_window_bounds_device": (C.c_int, [_P, C.POINTER(PackedReads), _P]),
     "msq_pileup_device_window": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), _P, C.c_int32, C.c_int32, _P, _P]),
-    "msq_reads_partition": (C.c_int, [_P, C.POINTER(PackedReads), C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "msq_reads_partition": (C.c_int, [_P, C.POINTER(PackedReads), C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "msq_partition_slabs": (C.c_int, [_P]),
     "msq_partition_view": (C.POINTER(PackedReads), [_P, C.c_int]),
     "msq_partition_free": (C.c_int, [_P, _P]),

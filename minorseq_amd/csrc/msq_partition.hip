@@ -16,12 +16,13 @@
 #include <new>
 #include <vector>
 
-void msq_slab_layout(int32_t W, int* n_slabs, int* Gslab);
+void msq_slab_layout(int32_t W, int max_words, int* n_slabs, int* Gslab);
 int msq_pileup_stream_slab_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
-                                  int32_t W, int slab, uint32_t* d_nuc, uint32_t* d_codon, bool* handled);
+                                  int32_t W, int slab, int slab_words, uint32_t* d_nuc, uint32_t* d_codon, bool* handled);
 
 struct msq_partition {
     int32_t win_begin0 = 0, W = 0;
+    int slab_words = 128;  // the layout's parameter: both the split and the launches use it
     std::vector<msq_packed_dev*> sets;
 };
 
@@ -139,21 +140,24 @@ extern "C" const msq_packed_reads* msq_partition_view(const msq_partition* p, in
     return (p && slab >= 0 && slab < (int)p->sets.size()) ? &p->sets[slab]->view : nullptr;
 }
 
-extern "C" int msq_reads_partition(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t win_begin0, int32_t W, msq_partition** out)
+extern "C" int msq_reads_partition(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t win_begin0, int32_t W,
+                                   int32_t max_slab_columns, msq_partition** out)
 {
     if (!ctx || !d_reads || !out) return msq_fail(MSQ_ERR_ARG, "msq_reads_partition: NULL argument");
     *out = nullptr;
     if (W < 0) return msq_fail(MSQ_ERR_ARG, "msq_reads_partition: negative window width %d", W);
     const uint64_t n = d_reads->n_reads;
     if (n && (!d_reads->ref_start || !d_reads->ref_end || !d_reads->group_off || !d_reads->bop)) return msq_fail(MSQ_ERR_ARG, "msq_reads_partition: NULL read arrays");
+    const int slab_words = max_slab_columns <= 0 ? 128 : std::min(128, std::max(1, max_slab_columns / 32));
     int n_slabs = 0, Gslab = 0;
-    msq_slab_layout(W, &n_slabs, &Gslab);
+    msq_slab_layout(W, slab_words, &n_slabs, &Gslab);
     if (n_slabs > kMaxSlabs) return msq_fail(MSQ_ERR_ARG, "msq_reads_partition: %d slabs (window of %d columns), at most %d", n_slabs, W, kMaxSlabs);
     MSQ_HIP(hipSetDevice(ctx->device));
     msq_partition* p = new (std::nothrow) msq_partition;
     if (!p) return msq_fail(MSQ_ERR_NOMEM, "msq_reads_partition: out of memory");
     p->win_begin0 = win_begin0;
     p->W = W;
+    p->slab_words = slab_words;
     void *d_first = nullptr, *d_cnt = nullptr, *d_off = nullptr, *d_rs = nullptr, *d_re = nullptr, *d_tmp = nullptr;
     auto fail = [&](int code, const char* what, hipError_t e) {
         (void)hipStreamSynchronize(ctx->stream);
@@ -267,7 +271,7 @@ extern "C" int msq_pileup_partition(msq_ctx* ctx, const msq_partition* p, const 
         const msq_packed_reads& v = p->sets[s]->view;
         if (v.n_reads == 0) continue;
         bool handled = false;
-        int rc = msq_pileup_stream_slab_launch(ctx, v, *thr, p->win_begin0, p->W, s, d_nuc, d_codon, &handled);
+        int rc = msq_pileup_stream_slab_launch(ctx, v, *thr, p->win_begin0, p->W, s, p->slab_words, d_nuc, d_codon, &handled);
         if (rc != MSQ_OK) return rc;
         if (!handled) return msq_fail(MSQ_ERR_ARG, "msq_pileup_partition: needs the streaming kernel (flags=%u)", v.flags);
     }

@@ -854,16 +854,18 @@ struct PhaseRequest {
 
 // The column slabs of a W-column window: windows wider than 128 words (4096 columns) are cut into equal slabs of
 // <= 128 words.  Slab s covers window columns [s * Gslab * 32, min(W, (s + 1) * Gslab * 32)).
-void msq_slab_layout(int32_t W, int* n_slabs, int* Gslab)
+// max_words: the widest slab wanted (1..128; a partition may ask for narrower slabs than the kernel's limit).
+void msq_slab_layout(int32_t W, int max_words, int* n_slabs, int* Gslab)
 {
     const int Gtot = (W + 31) / 32;
-    *n_slabs = Gtot ? (Gtot + 127) / 128 : 0;
+    const int cap = max_words < 1 ? 1 : max_words > 128 ? 128 : max_words;
+    *n_slabs = Gtot ? (Gtot + cap - 1) / cap : 0;
     *Gslab = *n_slabs ? (Gtot + *n_slabs - 1) / *n_slabs : 0;
 }
 
 static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
                          const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon, const PhaseRequest* phase, bool* handled,
-                         int only_slab = -1)
+                         int only_slab = -1, int slab_words = 128)
 {
     *handled = false;
     if (R.flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
@@ -874,7 +876,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     // the reads are streamed once per slab (a launch places only the bases that fall into its slab and margins)
     const int Gtot = (W + 31) / 32;
     int n_slabs = 0, Gslab = 0;
-    msq_slab_layout(W, &n_slabs, &Gslab);
+    msq_slab_layout(W, slab_words, &n_slabs, &Gslab);
 
     // the QV planes that can mask a base (threshold set and plane present; ArrayRead.inl:67-87), compacted
     StreamArgs a;
@@ -1002,9 +1004,9 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
 
 // one column slab only (msq_pileup_slab): the caller's read set need hold no bases outside that slab and its margins
 int msq_pileup_stream_slab_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
-                                  int32_t W, int slab, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
+                                  int32_t W, int slab, int slab_words, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
 {
-    return stream_launch(ctx, R, thr, win_begin0, W, nullptr, d_nuc, d_codon, nullptr, handled, slab);
+    return stream_launch(ctx, R, thr, win_begin0, W, nullptr, d_nuc, d_codon, nullptr, handled, slab, slab_words);
 }
 
 int msq_phase_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,

@@ -232,10 +232,10 @@ def pileup_device_window(ctx, dr, thr, bounds, begin0, W_max, nuc=None, codon=No
 class Partition:
     """msq_reads_partition: per column slab a packed read set of its own (library-owned HBM)."""
 
-    def __init__(self, ctx, dr, win_begin0, W):
+    def __init__(self, ctx, dr, win_begin0, W, max_slab_columns=0):
         self.ctx, self.win_begin0, self.W = ctx, win_begin0, W
         h = C.c_void_p()
-        abi.check(abi.lib().msq_reads_partition(ctx.h, dr.view, win_begin0, W, C.byref(h)))
+        abi.check(abi.lib().msq_reads_partition(ctx.h, dr.view, win_begin0, W, max_slab_columns, C.byref(h)))
         self._h = h
         self.n_slabs = abi.lib().msq_partition_slabs(h)
 
