@@ -48,6 +48,8 @@ int main(int argc, char** argv)
                                     source.names[r].c_str());
                     for (const auto& c : chems) std::printf("CHEMS %s\n", c.empty() ? "." : c.c_str());
                     Dump("bam", aac);
+                    aac.PhaseVariants();
+                    DumpReports("bam", aac);
                 }
             }
             if (time_only) {
@@ -109,6 +111,8 @@ int main(int argc, char** argv)
             Juliet::JulietSettings s;
             Juliet::AminoAcidCaller aac(reads, error, s);
             Dump("bam", aac);
+            aac.PhaseVariants();
+            DumpReports("bam", aac);
         }
     } catch (const std::exception& e) {
         std::printf("ERR %s\n", e.what());

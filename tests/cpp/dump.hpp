@@ -61,7 +61,13 @@ static void Dump(const char* name, Juliet::AminoAcidCaller& aac)
     std::fputs(ms.str().c_str(), stdout);
     std::printf("ENDMSATABLE\nERRMODE %s\n", name);
     std::ostringstream es;
-    Juliet::JulietWorkflow::Error(es, "input.bam", aac.msaByColumn_);
-    std::fputs(es.str().c_str(), stdout);
+    try {
+        Juliet::JulietWorkflow::Error(es, "input.bam", aac.msaByColumn_);
+        std::fputs(es.str().c_str(), stdout);
+    } catch (const std::out_of_range&) {
+        // a column whose majority is 'N' has MaxBase() ' ', and Frequency(' ') is counts_.at(255): the reference throws
+        // the same std::out_of_range (NucleotideConversion.h:84-85, MSA.inl:58-61)
+        std::printf("out_of_range\n");
+    }
     std::printf("ENDERRMODE\n");
 }

@@ -293,6 +293,12 @@ def test_direct_decode_equals_array_read_path(tmp_path, ref, rich, clean, region
         assert [(int(t[1]), int(t[2]), int(t[3]), t[5]) for t in src] == [(w[0], w[1], len(w[2]), w[5]) for w in want]
         body = lambda rest: [l for l in rest if l.split(" ")[0] in ("CASE", "BEGIN", "NUC", "CODON", "NTESTS", "VAR", "MSA", "PERF")]
         assert body(rest_d) == body(rest_a) and len(body(rest_a)) > 400
+        # ... and after PhaseVariants() the whole report, msa table and error-mode lines, text for text
+        report = lambda rest: rest[rest.index("JSON bam"):rest.index("ENDERRMODE") + 1]
+        assert report(rest_d) == report(rest_a) and len(report(rest_a)) > 100
+        import json
+        rep = json.loads("\n".join(rest_d[rest_d.index("JSON bam") + 1:rest_d.index("ENDJSON")]))
+        assert sorted(rep) == ["genes", "haplotype_read_counts", "haplotypes"]
         chems = [l.split(" ")[1] for l in rest_d if l.startswith("CHEMS ")]
         assert chems == [CHEM["abcd1234"]]
     else:
