@@ -16,7 +16,8 @@
 // Per-read rows (MSAByRow::Rows()/NameToRow) are not materialised: PhaseVariants, their one consumer, gets the
 // codons it asks for from the device (MSAByRow::PhaseKeys).  Also here: the JSON report
 // (msq_json.hpp), the --msa / --mode-error writers, MSAColumn::Insertions() and PacBio::Fuse::Fuse
-// (include/pacbio/fuse/Fuse.h:50-72).  Not mirrored: TargetConfig JSON parsing, the HTML report.
+// (include/pacbio/fuse/Fuse.h:50-72), TargetConfig(input) from a JSON string or file.  Not mirrored: the HTML
+// report, the reference's built-in HIV configuration tables.
 //
 // Errors: ABI status codes come back as the reference's exceptions -- std::runtime_error("Unexpected cigar ..") /
 // ("Unexpected base ..") (src/MSA.cpp:85,182), std::out_of_range (referenceSequence.substr,
@@ -26,7 +27,11 @@
 
 #include <algorithm>
 #include <array>
+#include <cctype>
 #include <cmath>
+#include <fstream>
+#include <iostream>
+#include <iterator>
 #include <cstddef>
 #include <cstdint>
 #include <exception>
@@ -554,8 +559,108 @@ struct TargetGene  // TargetConfig.h:95-113; begin/end are 1-based reference coo
     std::vector<DRM> drms;
     std::vector<ExpectedMinor> minors;
 };
-struct TargetConfig  // TargetConfig.h:117-139 (data members; JSON parsing stays with the caller)
+struct TargetConfig  // TargetConfig.h:117-139, src/TargetConfig.cpp:120-265
 {
+    TargetConfig() = default;
+    /// From a JSON string ("{...}") or the path of a JSON file, optionally wrapped in <>, "" or '' as the CLI passes
+    /// it (DetermineConfigInput, src/TargetConfig.cpp:134-167).  The reference also knows two built-in tags ("HIV",
+    /// "HIV-PB": HXB2 with the HIVdb resistance lists); those data are not part of this header -- pass the
+    /// configuration as a file or string -- and a tag is reported like any unknown input.
+    explicit TargetConfig(const std::string& input)
+    {
+        const std::string inputString = DetermineConfigInput(input);
+        if (!inputString.empty()) {
+            const JSON::Json inputJson = JSON::Json::parse(inputString);
+            targetGenes = TargetGenesFromJson(inputJson);
+            referenceSequence = RootTagFromJson(inputJson, "referenceSequence");
+            referenceName = RootTagFromJson(inputJson, "referenceName");
+            version = RootTagFromJson(inputJson, "version");
+            dbVersion = RootTagFromJson(inputJson, "databaseVersion");
+        }
+    }
+    static std::string DetermineConfigInput(std::string input)
+    {
+        if (input.empty()) return "";
+        if ((input.front() == '<' && input.back() == '>') || (input.front() == '"' && input.back() == '"') ||
+            (input.front() == '\'' && input.back() == '\''))
+            input = input.substr(1, input.size() - 2);
+        std::string output;
+        if (!input.empty() && input.front() == '{') {
+            output = input;
+        } else {
+            std::ifstream t(input);
+            if (t.good())
+                output.assign(std::istreambuf_iterator<char>(t), std::istreambuf_iterator<char>());
+            else
+                std::cerr << "Warning: Target config -c is not a file, JSON string, or tag: " << input << std::endl;
+        }
+        if (output.empty())
+            std::cerr << "Warning: Empty target config -c, specified region will be treated as coding region" << std::endl;
+        return output;
+    }
+    static std::string RootTagFromJson(const JSON::Json& root, const std::string& tag)
+    {
+        if (root.empty() || root.find(tag) == root.cend() || root.at(tag).empty()) return "";
+        return root.at(tag).AsString();
+    }
+    /// genes[]: name, begin, end (required); drms[]: name, positions[] -- "M184VI" expands to every (reference amino
+    /// acid, position, variant amino acid) combination, a missing side to '*'; expectedminors[]: position, aminoacid,
+    /// codon.  The error texts are the reference's (src/TargetConfig.cpp:186-262).
+    static std::vector<TargetGene> TargetGenesFromJson(const JSON::Json& root)
+    {
+        std::vector<TargetGene> genes;
+        if (root.empty() || root.find("genes") == root.cend() || root.at("genes").empty()) return genes;
+        auto has = [](const JSON::Json& j, const char* key) { return j.find(key) != j.cend(); };
+        for (const JSON::Json& jGene : root.at("genes").array()) {
+            if (!has(jGene, "name")) throw std::runtime_error("Missing name in gene.");
+            if (!has(jGene, "begin")) throw std::runtime_error("Missing begin in gene.");
+            if (!has(jGene, "end")) throw std::runtime_error("Missing end in gene.");
+            const std::string name = jGene.at("name").AsString();
+            std::vector<DRM> drms;
+            if (has(jGene, "drms")) {
+                for (const JSON::Json& jDrm : jGene.at("drms").array()) {
+                    DRM drm;
+                    if (!has(jDrm, "name")) throw std::runtime_error("Missing name in drm in gene " + name);
+                    drm.name = jDrm.at("name").AsString();
+                    if (!has(jDrm, "positions")) throw std::runtime_error("Missing positions in drm in gene " + name);
+                    if (jDrm.at("positions").empty()) throw std::runtime_error("Empty positions in drm in gene " + name);
+                    for (const JSON::Json& jp : jDrm.at("positions").array()) {
+                        const std::string& p = jp.AsString();
+                        // the first match of ([a-zA-Z]*)([0-9]+)([a-zA-Z]*): letters, digits, letters
+                        size_t d0 = 0;
+                        while (d0 < p.size() && !(p[d0] >= '0' && p[d0] <= '9')) ++d0;
+                        if (d0 == p.size()) continue;  // no digits: regex_search finds nothing
+                        size_t l0 = d0;
+                        while (l0 > 0 && std::isalpha(static_cast<unsigned char>(p[l0 - 1]))) --l0;
+                        size_t d1 = d0;
+                        while (d1 < p.size() && p[d1] >= '0' && p[d1] <= '9') ++d1;
+                        size_t l1 = d1;
+                        while (l1 < p.size() && std::isalpha(static_cast<unsigned char>(p[l1]))) ++l1;
+                        std::string refAAs = p.substr(l0, d0 - l0), curAAs = p.substr(d1, l1 - d1);
+                        if (refAAs.empty()) refAAs = "*";
+                        if (curAAs.empty()) curAAs = "*";
+                        const int pos = std::stoi(p.substr(d0, d1 - d0));
+                        for (const char a : refAAs)
+                            for (const char b : curAAs) drm.positions.emplace_back(a, pos, b);
+                    }
+                    drms.emplace_back(std::move(drm));
+                }
+            }
+            TargetGene g(static_cast<int>(jGene.at("begin").AsInt()), static_cast<int>(jGene.at("end").AsInt()), name, drms);
+            if (has(jGene, "expectedminors")) {
+                for (const JSON::Json& jMinor : jGene.at("expectedminors").array()) {
+                    if (!has(jMinor, "position")) throw std::runtime_error("Missing position in expectedminors in gene " + name);
+                    if (!has(jMinor, "aminoacid")) throw std::runtime_error("Missing aminoacid in expectedminors in gene " + name);
+                    if (!has(jMinor, "codon")) throw std::runtime_error("Missing codon in expectedminors in gene " + name);
+                    g.minors.push_back(ExpectedMinor{static_cast<int>(jMinor.at("position").AsInt()), jMinor.at("aminoacid").AsString(),
+                                                     jMinor.at("codon").AsString()});
+                }
+            }
+            genes.emplace_back(std::move(g));
+        }
+        return genes;
+    }
+
     std::vector<TargetGene> targetGenes;
     std::string referenceName, referenceSequence, version, dbVersion;
     size_t NumExpectedMinors() const
