@@ -984,7 +984,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
             MSQ_HIP(hipGetLastError());
             if (phase) continue;
             const int col_blocks = (G * 32 + 63) / 64;
-            const int slices = std::max(1, std::min(n_wg / 8, (2 * ctx->n_cu + col_blocks - 1) / col_blocks));
+            const int slices = std::max(1, std::min(n_wg / 32, (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
             hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(256), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
                                a.slab0, W, d_nuc, d_codon);
             MSQ_HIP(hipGetLastError());
