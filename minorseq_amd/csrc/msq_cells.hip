@@ -251,10 +251,12 @@ __device__ __forceinline__ int codon_count(const uint32_t* __restrict__ codon, i
     return (win_pos >= 1 && win_pos + 2 < W) ? (int)codon[(size_t)win_pos * 64 + lane] : 0;
 }
 
-// CountNumberOfTests, src/AminoAcidCaller.cpp:86-103: sum over positions of the number of distinct codons
+// CountNumberOfTests, src/AminoAcidCaller.cpp:86-103: sum over positions of the number of distinct codons; 0 -> 1
+// (:102).  acc = the context's small accumulators (sum, ticket), all zero between kernels: the workgroup that
+// draws the last ticket stores the finished number to n_tests and clears them.
 __global__ __launch_bounds__(1024) void count_tests_kernel(const int32_t* __restrict__ pos, int64_t P, int32_t begin1,
                                                           int32_t W, const uint32_t* __restrict__ codon,
-                                                          int32_t* __restrict__ n_tests)
+                                                          uint32_t* __restrict__ acc, int32_t* __restrict__ n_tests)
 {
     const int lane = threadIdx.x & 63;
     const int64_t p = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -267,7 +269,14 @@ __global__ __launch_bounds__(1024) void count_tests_kernel(const int32_t* __rest
     if (threadIdx.x == 0) {  // one atomic per block: same-address atomics serialise
         int n = 0;
         for (int k = 0; k < (int)(blockDim.x >> 6); ++k) n += s_n[k];
-        if (n) atomicAdd(n_tests, n);
+        if (n) atomicAdd(&acc[0], (uint32_t)n);
+        __threadfence();
+        if (atomicAdd(&acc[1], 1u) == gridDim.x - 1) {
+            __threadfence();
+            const uint32_t total = atomicExch(&acc[0], 0u);
+            atomicExch(&acc[1], 0u);
+            *n_tests = total == 0 ? 1 : (int32_t)total;
+        }
     }
 }
 
@@ -282,8 +291,7 @@ __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restri
     const int lane = threadIdx.x & 63;
     const int64_t p = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (p >= P) return;
-    int number_of_tests = *n_tests_raw;
-    if (number_of_tests == 0) number_of_tests = 1;  // :102
+    const int number_of_tests = *n_tests_raw;  // already 0 -> 1 (:102)
     const int gene = pos[p * 4 + 0], i = pos[p * 4 + 1], aa_pos = pos[p * 4 + 2], ref_from_seq = pos[p * 4 + 3];
     const int win_pos = i - begin1;  // :425
     const int cnt = codon_count(codon, win_pos, W, lane);
@@ -351,12 +359,6 @@ __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restri
     if (out_expected) out_expected[p * 64 + lane] = expected;
 }
 
-// numberOfTests == 0 ? 1 : numberOfTests, src/AminoAcidCaller.cpp:102 (applied after every reader of the raw sum)
-__global__ void finalize_tests_kernel(int32_t* __restrict__ n_tests)
-{
-    if (*n_tests == 0) *n_tests = 1;
-}
-
 extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t* d_codon, const msq_error_model* em,
                               double maximal_perc, msq_position* d_positions, double* d_p, double* d_expected,
                               int32_t* d_n_tests)
@@ -365,10 +367,9 @@ extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t
     if (plan->range_error)  // std::out_of_range from referenceSequence.substr, src/AminoAcidCaller.cpp:446
         return msq_fail(MSQ_ERR_RANGE, "basic_string::substr: a gene position lies outside the reference sequence");
     MSQ_HIP(hipSetDevice(ctx->device));
-    MSQ_HIP(hipMemsetAsync(d_n_tests, 0, sizeof(int32_t), ctx->stream));
-    if (plan->P == 0) {
-        hipLaunchKernelGGL(finalize_tests_kernel, dim3(1), dim3(1), 0, ctx->stream, d_n_tests);
-        MSQ_HIP(hipGetLastError());
+    if (plan->P == 0) {  // nothing to test: numberOfTests == 0 -> 1 (:102)
+        const int32_t one = 1;
+        MSQ_HIP(hipMemcpyAsync(d_n_tests, &one, sizeof(one), hipMemcpyHostToDevice, ctx->stream));
         return MSQ_OK;
     }
     if (!d_codon || !d_positions || !d_p) return msq_fail(MSQ_ERR_ARG, "msq_call_cells: NULL device buffer");
@@ -378,14 +379,12 @@ extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t
     }
     const unsigned blocks = (unsigned)((plan->P + 3) / 4);
     hipLaunchKernelGGL(count_tests_kernel, dim3((unsigned)((plan->P + 15) / 16)), dim3(1024), 0, ctx->stream, plan->d_pos, plan->P, plan->begin1,
-                       plan->W, d_codon, d_n_tests);
+                       plan->W, d_codon, ctx->d_small + 8, d_n_tests);
     MSQ_HIP(hipGetLastError());
     LFact lf{ctx->d_lfact, ctx->lfact_n};
     hipLaunchKernelGGL(call_cells_kernel, dim3(blocks), dim3(256), 0, ctx->stream, plan->d_pos, plan->P, plan->begin1,
                        plan->W, plan->has_reference ? 1 : 0, d_codon, lf, *em, maximal_perc, d_n_tests, d_positions, d_p,
                        d_expected, ctx->d_err);
-    MSQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(finalize_tests_kernel, dim3(1), dim3(1), 0, ctx->stream, d_n_tests);
     MSQ_HIP(hipGetLastError());
     return MSQ_OK;
 }

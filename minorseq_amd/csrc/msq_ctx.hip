@@ -42,8 +42,9 @@ extern "C" int msq_ctx_create(int device, msq_ctx** out)
     c->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cu = prop.multiProcessorCount;
-    hipError_t e = hipMalloc(&c->d_err, sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(c->d_err, 0, sizeof(uint32_t));
+    hipError_t e = hipMalloc(&c->d_err, 64 * sizeof(uint32_t));  // the error word + the small accumulators
+    if (e == hipSuccess) e = hipMemset(c->d_err, 0, 64 * sizeof(uint32_t));
+    c->d_small = c->d_err + 16;
     if (e != hipSuccess) {
         delete c;
         return msq_fail(MSQ_ERR_HIP, "msq_ctx_create: %s", hipGetErrorString(e));

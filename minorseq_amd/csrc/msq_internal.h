@@ -22,6 +22,11 @@ struct msq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t* d_err = nullptr;      // [1] deferred error bits
+    // [48] small accumulators of kernels that finish their own reduction: all zero between kernels -- the last
+    // workgroup of a kernel (atomic ticket) reads the result, hands it on and clears what it used, so no memset
+    // and no finishing kernel is launched.  [0..2] window bounds (keyed maxima, ticket), [4..5] their decoded
+    // result for the host, [8..9] number of tests (sum, ticket)
+    uint32_t* d_small = nullptr;
     double* d_lfact = nullptr;      // [lfact_n + 1] lgamma(n + 1.0)
     int64_t lfact_n = -1;
     int n_cu = 256;

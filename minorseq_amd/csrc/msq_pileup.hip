@@ -14,11 +14,13 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
                              bool* handled);
 
 // ------------------------------------------------------------------------------------------ window bounds
-// MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:138-142).  out[0] = max over reads of ~key(start),
-// out[1] = max of key(end), with key(x) = x ^ 0x80000000, the order-preserving map of int32 onto uint32: both
-// maxima start from 0, so one memset initialises them; the host decodes and applies endPos_'s initial value 0.
+// MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:138-142).  acc[0] = max over reads of ~key(start),
+// acc[1] = max of key(end), with key(x) = x ^ 0x80000000, the order-preserving map of int32 onto uint32: both
+// maxima start from 0.  acc lives in the context's small accumulators, which are all zero between kernels: the
+// workgroup that draws the last ticket (acc[2]) reads the maxima back through atomics, writes {-begin0, end0}
+// (endPos_ never drops below its initial 0) to `out` and clears acc -- no memset before, no kernel after.
 __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __restrict__ ref_start, const int32_t* __restrict__ ref_end,
-                                                            uint64_t n, uint32_t* __restrict__ out)
+                                                            uint64_t n, uint32_t* __restrict__ acc, int32_t* __restrict__ out)
 {
     int32_t lo = INT_MAX, hi = INT_MIN;
     const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, nthr = (uint64_t)gridDim.x * blockDim.x;
@@ -49,33 +51,28 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
             lo = min(lo, s_lo[k]);
             hi = max(hi, s_hi[k]);
         }
-        atomicMax(&out[0], ~((uint32_t)lo ^ 0x80000000u));
-        atomicMax(&out[1], (uint32_t)hi ^ 0x80000000u);
+        atomicMax(&acc[0], ~((uint32_t)lo ^ 0x80000000u));
+        atomicMax(&acc[1], (uint32_t)hi ^ 0x80000000u);
+        __threadfence();
+        if (atomicAdd(&acc[2], 1u) == gridDim.x - 1) {  // every other workgroup's maxima are in
+            __threadfence();
+            const uint32_t k_lo = atomicExch(&acc[0], 0u), k_hi = atomicExch(&acc[1], 0u);
+            atomicExch(&acc[2], 0u);
+            const int32_t begin0 = (int32_t)(~k_lo ^ 0x80000000u), end0 = (int32_t)(k_hi ^ 0x80000000u);
+            out[0] = -begin0;
+            out[1] = end0 > 0 ? end0 : 0;
+        }
     }
 }
 
-// The keyed maxima of all reads into the first 8 bytes of the context's scratch (enqueued, not waited for).
-static int launch_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, void** scratch)
+static int launch_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_out)
 {
-    int rc = msq_scratch(ctx, 64, scratch);
-    if (rc != MSQ_OK) return rc;
-    MSQ_HIP(hipMemsetAsync(*scratch, 0, 8, ctx->stream));
-    if (d_reads->n_reads == 0) return MSQ_OK;
     uint64_t blocks = (d_reads->n_reads / 4 + 255) / 256;
     blocks = blocks < 1 ? 1 : blocks > 128 ? 128 : blocks;  // few blocks: their same-address atomics serialise
     hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_reads->ref_start,
-                       d_reads->ref_end, d_reads->n_reads, (uint32_t*)*scratch);
+                       d_reads->ref_end, d_reads->n_reads, ctx->d_small, d_out);
     MSQ_HIP(hipGetLastError());
     return MSQ_OK;
-}
-
-// {-begin0, end0} from the keyed maxima; no reads: begin0 = INT_MAX, end0 = 0 (MSA.h:83-84)
-__global__ void window_bounds_decode_kernel(const uint32_t* __restrict__ keyed, uint64_t n_reads, int32_t* __restrict__ out)
-{
-    const int32_t begin0 = n_reads ? (int32_t)(~keyed[0] ^ 0x80000000u) : INT_MAX;
-    const int32_t hi = n_reads ? (int32_t)(keyed[1] ^ 0x80000000u) : 0;
-    out[0] = -begin0;
-    out[1] = hi > 0 ? hi : 0;
 }
 
 extern "C" int msq_window_bounds_device(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_bounds)
@@ -83,12 +80,12 @@ extern "C" int msq_window_bounds_device(msq_ctx* ctx, const msq_packed_reads* d_
     if (!ctx || !d_reads || !d_bounds) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds_device: NULL argument");
     if (d_reads->n_reads && (!d_reads->ref_start || !d_reads->ref_end)) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds_device: NULL ref arrays");
     MSQ_HIP(hipSetDevice(ctx->device));
-    void* s = nullptr;
-    int rc = launch_window_bounds(ctx, d_reads, &s);
-    if (rc != MSQ_OK) return rc;
-    hipLaunchKernelGGL(window_bounds_decode_kernel, dim3(1), dim3(1), 0, ctx->stream, (const uint32_t*)s, d_reads->n_reads, d_bounds);
-    MSQ_HIP(hipGetLastError());
-    return MSQ_OK;
+    if (d_reads->n_reads == 0) {  // MSAByRow defaults (include/pacbio/data/MSA.h:83-84): begin INT_MAX, end 0
+        const int32_t none[2] = {-INT_MAX, 0};
+        MSQ_HIP(hipMemcpyAsync(d_bounds, none, sizeof(none), hipMemcpyHostToDevice, ctx->stream));
+        return MSQ_OK;
+    }
+    return launch_window_bounds(ctx, d_reads, d_bounds);
 }
 
 extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* begin0, int32_t* end0)
@@ -99,15 +96,14 @@ extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, 
     *end0 = 0;
     if (d_reads->n_reads == 0) return MSQ_OK;
     if (!d_reads->ref_start || !d_reads->ref_end) return msq_fail(MSQ_ERR_ARG, "msq_window_bounds: NULL ref arrays");
-    void* s = nullptr;
-    int rc = launch_window_bounds(ctx, d_reads, &s);
+    int32_t* d_res = reinterpret_cast<int32_t*>(ctx->d_small + 4);
+    int rc = launch_window_bounds(ctx, d_reads, d_res);
     if (rc != MSQ_OK) return rc;
-    uint32_t res[2];
-    MSQ_HIP(hipMemcpyAsync(res, s, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
+    int32_t res[2];
+    MSQ_HIP(hipMemcpyAsync(res, d_res, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     MSQ_HIP(hipStreamSynchronize(ctx->stream));
-    *begin0 = (int32_t)(~res[0] ^ 0x80000000u);
-    const int32_t hi = (int32_t)(res[1] ^ 0x80000000u);
-    *end0 = hi > 0 ? hi : 0;  // UpdateBoundaries only ever raises endPos_ from 0 (src/MSA.cpp:138-142)
+    *begin0 = -res[0];
+    *end0 = res[1];  // UpdateBoundaries only ever raises endPos_ from 0 (src/MSA.cpp:138-142)
     return MSQ_OK;
 }
 
