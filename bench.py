@@ -40,6 +40,8 @@ def parse():
                     "hiv_mix_200k, amp20k_10m")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
     ap.add_argument("--qualqv", type=int, default=-1, help="QUALQV threshold (env var of the reference); -1 = unset")
+    ap.add_argument("--no-bake", action="store_true", help="with --qualqv: keep the QV plane and apply the threshold "
+                    "inside every pileup pass instead of once at set-up (msq_reads_bake_qv)")
     ap.add_argument("--mode", default="auto", choices=["auto", "simple", "stream"])
     ap.add_argument("--host-bounds", action="store_true", help="bring the window bounds back to the host every step "
                     "(msq_window_bounds + msq_pileup) instead of leaving them in HBM (msq_window_bounds_device + "
@@ -57,14 +59,14 @@ def parse():
     return ap.parse_args()
 
 
-def load_traffic(kernel, workload, reads, qualqv):
+def load_traffic(kernel, workload, reads, qualqv, baked=False):
     """HBM bytes per launch from the committed PMC passes (profiles/traffic.json; rocprofv3 cannot run inside the
     timed process), or None when no pass was recorded for this exact kernel / workload / size / QV setting."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             for e in json.load(f)["entries"]:
                 if (e["kernel"] == kernel and e["workload"] == workload and e["reads"] == reads
-                        and e.get("qualqv") == (None if qualqv < 0 else qualqv)):
+                        and e.get("qualqv") == (None if qualqv < 0 else qualqv) and bool(e.get("baked")) == baked):
                     return e["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -151,6 +153,14 @@ def main():
     # ---- setup (untimed): reads into HBM, plan, log-factorial table
     dr = device.synth_device(ctx, wl, rank * reads, reads)
     n_bases = dr.n_groups * 32
+    # a run's QV thresholds are fixed before the reads are loaded: they are applied once, at pack time (untimed like
+    # the packing itself), and the passes below stream the baked set -- as the front does (MSAByRow::Finish)
+    baked = a.qualqv >= 0 and not a.no_bake and a.h2d_steps == 0
+    if baked:
+        src = dr
+        dr = device.bake_qv(ctx, src, thr)
+        ctx.sync()
+        del src
     b0, e0 = sharding.allreduce_bounds(*device.window_bounds(ctx, dr), "cuda")
     W = e0 - b0
     gb, ge = wl.gene_arrays()
@@ -267,9 +277,10 @@ def main():
                 "window_bounds": "host round trip per step" if step is step_host_bounds else "device-resident",
                 "column_slabs": (part.n_slabs if part else (((W + 31) // 32) + 127) // 128),
                 "read_layout": "column-slab partition (built at set-up)" if part else "one read set",
+                "qv_thresholds": "unset" if a.qualqv < 0 else "applied at pack time (baked)" if baked else "applied in every pass",
                 "bases_per_gpu": int(n_bases), "codon_positions": plan.P, "number_of_tests": int(plan.n_tests.item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kernel_name, wl.name, reads, a.qualqv),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kernel_name, wl.name, reads, a.qualqv, baked),
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
         }
         if cpu is not None:

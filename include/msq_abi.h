@@ -97,6 +97,7 @@ typedef struct msq_packed_reads {
 #define MSQ_READS_NORMALIZED 2u /* inside every group the column-consuming bases come first (see above) */
 #define MSQ_READS_PAD_MARKED 4u /* plain layout whose padding slots carry op 3 + nucleotide code 3 ('P' / 'S' carry
                                    code 0): the end of a read can be told from a 'P' / 'S' op (msq_insertion_*) */
+#define MSQ_READS_QV_BAKED 8u   /* made by msq_reads_bake_qv: QV-failing match bases already read 'N', no QV planes */
 
 /* QvThresholds (include/pacbio/data/QvThresholds.h:44-54, src/QvThresholds.cpp:45-56): -1 = boost::none. */
 typedef struct msq_qv_thresholds {
@@ -120,6 +121,13 @@ typedef struct msq_packed_dev msq_packed_dev;
 int msq_reads_upload(msq_ctx* ctx, const msq_packed_reads* host_reads, msq_packed_dev** out);
 const msq_packed_reads* msq_packed_dev_view(const msq_packed_dev* p);
 int msq_packed_dev_free(msq_ctx* ctx, msq_packed_dev* p);
+/* The QV thresholds applied once, at pack time: a new device set (the caller keeps and frees the source) in which
+ * every '=' / 'X' base that misses a threshold -- ArrayBase::MeetQVThresholds false, ArrayRead.inl:67-87 -- is a
+ * literal 'N', the row char MSAByRow::AddRead writes for it (src/MSA.cpp:163-166), and which carries no QV planes.
+ * msq_pileup / msq_phase_codons / msq_reads_partition on the result with any thresholds give what the source gives
+ * under `thr`, bit for bit, from 0.5 instead of 1.5 .. 4.5 bytes per base.  The thresholds of a juliet run are
+ * fixed before the reads are loaded (JulietSettings), so the front bakes right after packing.  Asynchronous. */
+int msq_reads_bake_qv(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, msq_packed_dev** out);
 
 /* One ArrayBase (include/pacbio/data/ArrayRead.h:96-119) as an 8-byte record: the boost::optional QVs become a
  * presence byte + value.  has_qual covers qual; has_rich covers del, sub and ins (ArrayRead.h:98-101 sets all

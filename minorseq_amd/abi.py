@@ -16,6 +16,7 @@ MSQ_PILEUP_AUTO, MSQ_PILEUP_SIMPLE, MSQ_PILEUP_STREAM = 0, 1, 2
 MSQ_READS_HAS_EXOTIC = 1
 MSQ_READS_NORMALIZED = 2
 MSQ_READS_PAD_MARKED = 4
+MSQ_READS_QV_BAKED = 8
 MSQ_PACK_PLAIN = 1
 
 
@@ -94,6 +95,7 @@ _SIGNATURES = {
     "msq_packed_host_free": (C.c_int, [_P]),
     "msq_reads_upload": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(_P)]),
     "msq_packed_dev_view": (C.POINTER(PackedReads), [_P]),
+    "msq_reads_bake_qv": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.POINTER(_P)]),
     "msq_packed_dev_free": (C.c_int, [_P, _P]),
     "msq_pack_reads_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(_P)]),
     "msq_pack_reads_device_fill": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(_P)]),

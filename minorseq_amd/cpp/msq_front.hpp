@@ -384,6 +384,21 @@ private:
         struct EmptyTag { bool empty() const { return value; } bool value; } reads{noReads};
         msq_ctx* ctx = Msq::Context();
         dev_.reset(dev, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // kept for PhaseKeys
+        thr_ = msq_qv_thresholds{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
+        {
+            // The thresholds are fixed for the life of the MSA: apply them once (failing match bases become the 'N'
+            // AddRead writes, src/MSA.cpp:165-166) and let the QV planes go -- the pileup, the phasing gather and
+            // every later pass then stream 0.5 bytes per base.
+            const msq_packed_reads* v = msq_packed_dev_view(dev);
+            const bool masks = (thr_.qual >= 0 && v->qual) || (thr_.del >= 0 && v->delqv) || (thr_.sub >= 0 && v->subqv) ||
+                               (thr_.ins >= 0 && v->insqv);
+            if (masks) {
+                msq_packed_dev* baked = nullptr;
+                Msq::Check(msq_reads_bake_qv(ctx, v, &thr_, &baked));
+                dev_.reset(baked, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // frees the source
+                dev = baked;
+            }
+        }
         {
             int32_t b0 = 0, e0 = 0;
             Msq::Check(msq_window_bounds(ctx, msq_packed_dev_view(dev), &b0, &e0));
@@ -392,7 +407,6 @@ private:
             endPos_ = e0;
             dNuc_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 6));
             dCodon_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 64));
-            thr_ = msq_qv_thresholds{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
             Msq::Check(msq_pileup(ctx, msq_packed_dev_view(dev), &thr_, b0, width_, dNuc_->get(), dCodon_->get(), MSQ_PILEUP_AUTO));
             Msq::Check(msq_pileup_check(ctx));  // "Unexpected base ..." -> std::runtime_error
             nuc_ = dNuc_->ToHost();

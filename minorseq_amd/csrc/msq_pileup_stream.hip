@@ -377,11 +377,13 @@ struct BatchConsumer {
 
 // PHASE = false: the pileup.  PHASE = true: phase 1 only, then the per-read gather of AminoAcidCaller::PhaseVariants
 // (MSARow::CodonAt at the requested positions, src/AminoAcidCaller.cpp:149-160) instead of the counting.
-template <int NP, int PASSES, bool PHASE>
+// MANY_N: Ns are common (a QV mask, applied here or baked into the planes at pack time): they get a counter of
+// their own instead of going down the deviation path.
+template <int NP, int PASSES, bool PHASE, bool MANY_N = (NP != 0)>
 __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(StreamArgs a)
 {
     constexpr int NS = slots_of(NP, PASSES);
-    constexpr bool COUNT_N = NP != 0;  // Ns are common only under a QV mask
+    constexpr bool COUNT_N = MANY_N;
     constexpr int NC = COUNT_N ? 4 : 3;
     extern __shared__ __align__(16) uint32_t lds[];
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, NWV = T >> 6;
@@ -828,8 +830,9 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const uint32_t* __re
 
 typedef void (*pileup_kernel_fn)(StreamArgs);
 
-pileup_kernel_fn pick_kernel(int np, int passes)
+pileup_kernel_fn pick_kernel(int np, int passes, bool many_n)
 {
+    if (np == 0 && many_n) return passes == 1 ? pileup_kernel<0, 1, false, true> : pileup_kernel<0, 2, false, true>;
     if (passes == 1) {
         return np == 0   ? pileup_kernel<0, 1, false>
                : np == 1 ? pileup_kernel<1, 1, false>
@@ -894,7 +897,8 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
         a.qv[k] = np ? a.qv[np - 1] : nullptr;
         a.thr[k] = np ? a.thr[np - 1] : -1;
     }
-    const int NC = np_kernel == 0 ? 3 : 4;
+    const bool many_n = np_kernel != 0 || (R.flags & MSQ_READS_QV_BAKED) != 0;  // a QV mask makes Ns common
+    const int NC = many_n ? 4 : 3;
 
     a.ref_start = R.ref_start;
     a.group_off = R.group_off;
@@ -943,7 +947,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
         if (nwv < 1) return msq_fail(MSQ_ERR_ARG, "msq_pileup: no LDS for a %d-word slab", G);
         // the pileup's counters hold 1023 reads per wave and launch; the gather has no such limit
         const uint64_t reads_per_launch = phase ? R.n_reads : (uint64_t)ctx->n_cu * nwv * kMaxBatchesPerWave * kRows;
-        pileup_kernel_fn kern = phase ? pick_phase_kernel(np_kernel) : pick_kernel(np_kernel, passes);
+        pileup_kernel_fn kern = phase ? pick_phase_kernel(np_kernel) : pick_kernel(np_kernel, passes, many_n);
         if (phase) {
             void* s = nullptr;
             int rc = msq_scratch(ctx, (size_t)ph_n * 8, &s);

@@ -138,6 +138,54 @@ class DeviceReads:
         return sum(t.numel() * t.element_size() for t in self.t.values() if t is not None)
 
 
+class LibReads:
+    """A packed set in HBM that the library owns (msq_packed_dev): the attributes of DeviceReads the harness uses."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self.handle = ctx, handle
+        v = abi.lib().msq_packed_dev_view(handle).contents
+        self.view = abi.PackedReads.from_buffer_copy(v)
+        self.n_reads, self.n_groups, self.flags = int(v.n_reads), int(v.n_groups), int(v.flags)
+
+    def n_bytes(self):
+        planes = sum(1 for f in ("qual", "delqv", "subqv", "insqv") if getattr(self.view, f))
+        return self.n_reads * 8 + (self.n_reads + 1) * 8 + self.n_groups * (16 + 32 * planes)
+
+    def download(self):
+        """-> dict of numpy arrays in the pack_host() layout."""
+        L, v, n, g = abi.lib(), self.view, self.n_reads, self.n_groups
+
+        def back(addr, dtype, count):
+            if not addr:
+                return None
+            a = np.zeros(count, dtype=dtype)
+            if count:
+                abi.check(L.msq_memcpy_d2h(self.ctx.h, abi.ptr(a), addr, a.nbytes))
+            return a
+        return {"n_reads": n, "n_groups": g, "ref_start": back(v.ref_start, np.int32, n), "ref_end": back(v.ref_end, np.int32, n),
+                "group_off": back(v.group_off, np.uint64, n + 1), "bop": back(v.bop, np.uint32, g * 4),
+                "qual": back(v.qual, np.uint8, g * 32), "delqv": back(v.delqv, np.uint8, g * 32),
+                "subqv": back(v.subqv, np.uint8, g * 32), "insqv": back(v.insqv, np.uint8, g * 32), "flags": self.flags}
+
+    def close(self):
+        if self.handle is not None:
+            abi.lib().msq_packed_dev_free(self.ctx.h, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def bake_qv(ctx, dr, thr):
+    """msq_reads_bake_qv: the set with the thresholds applied (QV-failing match bases read 'N', no QV planes)."""
+    h = C.c_void_p()
+    abi.check(abi.lib().msq_reads_bake_qv(ctx.h, dr.view, thr, C.byref(h)))
+    return LibReads(ctx, h)
+
+
 def upload(packed, device=0):
     dev = torch.device("cuda", device)
     t = {}
