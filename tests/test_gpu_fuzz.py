@@ -50,6 +50,15 @@ def test_fuzz(ctx, seed):
             assert (nuc.cpu().numpy()[:m.W * 6].reshape(-1, 6) == m.nuc_counts()).all(), plain
             assert (codon.cpu().numpy()[:m.W * 64].reshape(-1, 64) == m.codon_counts()).all(), plain
             codon = codon[:m.W * 64].contiguous()
+        baked = device.bake_qv(ctx, dr, q)  # thresholds applied at pack time: same counts with no thresholds left
+        for mode in (abi.MSQ_PILEUP_AUTO, abi.MSQ_PILEUP_SIMPLE):
+            nuc, codon = device.pileup(ctx, baked, abi.QvThresholds.make(-1, -1, -1, -1), b0, m.W, mode=mode)
+            assert (nuc.cpu().numpy()[:m.W * 6].reshape(-1, 6) == m.nuc_counts()).all(), ("baked", plain, mode)
+            assert (codon.cpu().numpy()[:m.W * 64].reshape(-1, 64) == m.codon_counts()).all(), ("baked", plain, mode)
+        codon = codon[:m.W * 64].contiguous()
+        if plain:
+            assert device.insertion_counts(ctx, baked, b0, m.W).tolist() == device.insertion_counts(ctx, dr, b0, m.W).tolist()
+        baked.close()
         if plain:
             counts = device.insertion_counts(ctx, dr, b0, m.W)
             hist = [dict() for _ in range(m.W)]
