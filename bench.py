@@ -40,6 +40,8 @@ def parse():
                     "hiv_mix_200k, amp20k_10m")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
     ap.add_argument("--qualqv", type=int, default=-1, help="QUALQV threshold (env var of the reference); -1 = unset")
+    ap.add_argument("--rich", action="store_true", help="reads carry DelQV / SubQV / InsQV as well (4.5 B/base) and the "
+                    "reference's default SUBQV=42 applies (src/QvThresholds.cpp:45-56)")
     ap.add_argument("--no-bake", action="store_true", help="with --qualqv: keep the QV plane and apply the threshold "
                     "inside every pileup pass instead of once at set-up (msq_reads_bake_qv)")
     ap.add_argument("--mode", default="auto", choices=["auto", "simple", "stream"])
@@ -143,11 +145,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         sharding.FORCE_COLLECTIVES = a.force_dist
 
-    wl = synth.workload(a.workload)
+    wl = synth.workload(a.workload, rich_qv=True) if a.rich else synth.workload(a.workload)
     reads = a.reads or wl.n_reads
     ctx = device.Ctx(local)
     L = abi.lib()
-    thr = abi.QvThresholds.make(qual=a.qualqv)
+    thr = abi.QvThresholds.make(qual=a.qualqv, sub=42 if a.rich else -1)
     mode = {"auto": abi.MSQ_PILEUP_AUTO, "simple": abi.MSQ_PILEUP_SIMPLE, "stream": abi.MSQ_PILEUP_STREAM}[a.mode]
 
     # ---- setup (untimed): reads into HBM, plan, log-factorial table
@@ -155,7 +157,7 @@ def main():
     n_bases = dr.n_groups * 32
     # a run's QV thresholds are fixed before the reads are loaded: they are applied once, at pack time (untimed like
     # the packing itself), and the passes below stream the baked set -- as the front does (MSAByRow::Finish)
-    baked = a.qualqv >= 0 and not a.no_bake and a.h2d_steps == 0
+    baked = (a.qualqv >= 0 or a.rich) and not a.no_bake and a.h2d_steps == 0
     if baked:
         src = dr
         dr = device.bake_qv(ctx, src, thr)
@@ -256,7 +258,13 @@ def main():
         dt = float(t[0])
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
-        alg_bytes = wl.algorithmic_bytes(n_reads=reads)  # N * (1.001 * W * 1.5 + 12)
+        # N * (1.001 * W * 1.5 + 12) -- bit planes + one QV byte per base.  Rich reads are priced by the QV
+        # planes a threshold makes the pass read (never the 4.5 B/base of planes nobody looks at), a baked set like
+        # the QualQV-only case.
+        planes = (1 if a.qualqv >= 0 else 0) + (1 if a.rich else 0)
+        per_base = 1.5 if (baked or planes <= 1) else 0.5 + planes
+        alg_bytes = reads * 1.001 * wl.W * per_base + 12.0 * reads
+        assert a.rich or abs(alg_bytes - wl.algorithmic_bytes(n_reads=reads)) < 1.0
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         kernel_name = "pileup_simple_kernel" if a.mode == "simple" else "pileup_kernel"
         out = {
@@ -273,14 +281,14 @@ def main():
             "dtype": "u32 counts, f64 Fisher",
             "data": "synthetic",
             "config": {"workload": "%s: %d reads/GPU x %d columns (HXB2 pol, 1%% minors), QUALQV=%s" % (
-                wl.name, reads, W, "unset" if a.qualqv < 0 else a.qualqv), "mode": a.mode,
+                wl.name, reads, W, "unset" if a.qualqv < 0 else a.qualqv) + (", rich QVs, SUBQV=42" if a.rich else ""), "mode": a.mode,
                 "window_bounds": "host round trip per step" if step is step_host_bounds else "device-resident",
                 "column_slabs": (part.n_slabs if part else (((W + 31) // 32) + 127) // 128),
                 "read_layout": "column-slab partition (built at set-up)" if part else "one read set",
-                "qv_thresholds": "unset" if a.qualqv < 0 else "applied at pack time (baked)" if baked else "applied in every pass",
+                "qv_thresholds": "unset" if a.qualqv < 0 and not a.rich else "applied at pack time (baked)" if baked else "applied in every pass",
                 "bases_per_gpu": int(n_bases), "codon_positions": plan.P, "number_of_tests": int(plan.n_tests.item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": load_traffic(kernel_name, wl.name, reads, a.qualqv, baked),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if a.rich else load_traffic(kernel_name, wl.name, reads, a.qualqv, baked),
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
         }
         if cpu is not None:
