@@ -27,7 +27,21 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
     const uint64_t n4 = (((uintptr_t)ref_start | (uintptr_t)ref_end) & 15u) ? 0 : n / 4;  // 16-byte loads when aligned
     const int4* s4 = reinterpret_cast<const int4*>(ref_start);
     const int4* e4 = reinterpret_cast<const int4*>(ref_end);
-    for (uint64_t i = tid; i < n4; i += nthr) {
+    uint64_t i = tid;
+    for (; i + 3 * nthr < n4; i += 4 * nthr) {  // eight independent loads in flight per thread: the kernel is latency-bound
+        int4 s[4], e[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[k] = s4[i + k * nthr];
+            e[k] = e4[i + k * nthr];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo = min(min(lo, s[k].x), min(s[k].y, min(s[k].z, s[k].w)));
+            hi = max(max(hi, e[k].x), max(e[k].y, max(e[k].z, e[k].w)));
+        }
+    }
+    for (; i < n4; i += nthr) {
         const int4 s = s4[i], e = e4[i];
         lo = min(min(lo, s.x), min(s.y, min(s.z, s.w)));
         hi = max(max(hi, e.x), max(e.y, max(e.z, e.w)));
