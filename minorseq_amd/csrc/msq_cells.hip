@@ -199,21 +199,20 @@ __device__ double d_fisher_wave(double base_p, int a, int b, int c, int d, int l
     const int n = max_co - a;  // steps k = 0 .. n-1 multiply by factorInc(a+k, b-k, c-k, d+k); n = min(b, c) >= 1
     const int B = (n + 63) >> 6;
     const int k0 = min(n, lane * B), k1 = min(n, k0 + B);
-    double prod = 1.0;
-    for (int k = k0; k < k1; ++k) prod *= d_factor_inc(a + k, b - k, c - k, d + k);
+    double prod = 1.0, lsum = 0.0;  // the block's product and its terms summed in units of the product before the block
+    for (int k = k0; k < k1; ++k) {
+        prod *= d_factor_inc(a + k, b - k, c - k, d + k);
+        lsum += prod;
+    }
     double incl = prod;
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) {
         const double t = __shfl_up(incl, dd);
         if (lane >= dd) incl *= t;
     }
-    double curr = __shfl_up(incl, 1);  // product of every step before this lane's block
-    if (lane == 0) curr = 1.0;
-    double sum = 0.0;
-    for (int k = k0; k < k1; ++k) {
-        curr *= d_factor_inc(a + k, b - k, c - k, d + k);
-        sum += curr;
-    }
+    double before = __shfl_up(incl, 1);  // product of every step before this lane's block
+    if (lane == 0) before = 1.0;
+    double sum = before * lsum;
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) sum += __shfl_xor(sum, dd);
     return base_p + base_p * sum;
