@@ -35,7 +35,7 @@
 
 // MSQ_EXP: compile-time timing experiments only (make EXTRA=-DMSQ_EXP=n); any non-zero value gives WRONG counts.
 // bit 0 skip the LDS ORs of phase 1, bit 1 skip phase 2 + drain, bit 2 skip the squeeze, bit 3 skip the drain,
-// bit 4 skip zero_rows.  The shipped library is always built with 0.
+// bit 4 skip zero_rows, bit 5 skip the counter transposition of the flush.  The shipped library is always built with 0.
 #ifndef MSQ_EXP
 #define MSQ_EXP 0
 #endif
@@ -749,12 +749,12 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         if (my_err) atomicOr(a.err, my_err);
         return;
     }
-    // ---- flush: per column the guide's nucleotide / codon bins (meta), then the bit-sliced counters transposed
-    // and reduced over the waves through LDS, stored as this workgroup's partial
+    // ---- flush: per column the guide's nucleotide / codon bins (meta); then the waves' bit-sliced counters are added
+    // up while still bit-sliced (two bitop3 per level and counter, against some sixty instructions per counter to
+    // transpose it), one wave per counter, and only the sum is transposed and stored as this workgroup's partial
     __syncthreads();
     const int cols = G * 32;
     uint32_t* const part = a.partials + (size_t)blockIdx.x * (NC + 1) * cols;
-    uint32_t* const acc = lds;  // [cols], over the rows (no wave needs them any more)
     auto gbit = [&](int plane, int c) -> uint32_t { return (gl[(c >> 5) * 4 + plane] >> (c & 31)) & 1u; };
     for (int c = tid; c < cols; c += T) {
         const uint32_t v0 = gbit(0, c), v1 = gbit(0, c + 1), v2 = gbit(0, c + 2);
@@ -762,24 +762,70 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
                        k2 = gbit(1, c + 2) | (gbit(2, c + 2) << 1);
         part[(size_t)NC * cols + c] = k0 | (v0 << 2) | (((k0 << 4) | (k1 << 2) | k2) << 8) | ((v0 & v1 & v2) << 14);
     }
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        for (int i = tid; i < cols; i += T) acc[i] = 0;
-        __syncthreads();
-#pragma unroll
+    // The kernels that carry QV planes through the loop sit at the register limit: they keep the plain flush (every
+    // wave transposes its own counters and adds them into LDS accumulators); a run normally bakes the thresholds
+    // at pack time and never gets there.
+    constexpr bool SLICED_FLUSH = NP == 0;
+    if constexpr (SLICED_FLUSH) {
+        constexpr int SL = kLevels + 5;  // levels of a sum over <= 16 waves x 2 row halves
+        uint32_t* const slab = lds;      // [NC][NWV][kLevels][64] (the launcher sizes the LDS for it; rows and guide are dead)
+    #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            if (act[p]) {
-                for (int j = 0; j < 32; ++j) {
-                    uint32_t v = 0;
-#pragma unroll
-                    for (int l = 0; l < kLevels; ++l) v |= ((cnt[p][k][l] >> j) & 1u) << l;
-                    if (v) atomicAdd(&acc[cgp[p] * 32 + j], v);
+            __syncthreads();  // the guide words / the previous pass's sums have been read
+    #pragma unroll
+            for (int k = 0; k < NC; ++k)
+    #pragma unroll
+                for (int l = 0; l < kLevels; ++l) slab[((k * NWV + wave) * kLevels + l) * 64 + lane] = cnt[p][k][l];
+            __syncthreads();
+            // in a split pass lanes L and L + 32 counted different rows of the same word: two entries per wave
+            const bool sp = p == PASSES - 1 && split;
+            const bool mine = act[p] && (!sp || lane < 32);
+            for (int k = wave; k < NC && !(MSQ_EXP & 32); k += NWV) {  // wave-uniform
+                uint32_t sum[SL];
+    #pragma unroll
+                for (int l = 0; l < SL; ++l) sum[l] = 0;
+                for (int e = 0; e < (sp ? 2 * NWV : NWV); ++e) {
+                    const uint32_t* src = slab + (k * NWV + (sp ? e >> 1 : e)) * kLevels * 64 + ((lane + (sp ? 32 * (e & 1) : 0)) & 63);
+                    uint32_t carry = 0;
+    #pragma unroll
+                    for (int l = 0; l < SL; ++l) csa(sum[l], l < kLevels ? src[l * 64] : 0u, carry, sum[l], carry);
+                }
+                if (mine) {
+                    uint4* dst = reinterpret_cast<uint4*>(part + (size_t)k * cols + cgp[p] * 32);
+                    for (int j = 0; j < 32; j += 4) {
+                        uint32_t v[4] = {0, 0, 0, 0};
+    #pragma unroll
+                        for (int l = 0; l < SL; ++l) {
+                            const uint32_t nib = (sum[l] >> j) & 15u;
+    #pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] |= ((nib >> i) & 1u) << l;
+                        }
+                        dst[j >> 2] = make_uint4(v[0], v[1], v[2], v[3]);
+                    }
                 }
             }
         }
-        __syncthreads();
-        for (int i = tid; i < cols; i += T) part[(size_t)k * cols + i] = acc[i];
-        __syncthreads();
+    } else {
+        uint32_t* const acc = lds;  // [cols], over the rows (no wave needs them any more)
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            for (int i = tid; i < cols; i += T) acc[i] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                if (act[p] && !(MSQ_EXP & 32)) {
+                    for (int j = 0; j < 32; ++j) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int l = 0; l < kLevels; ++l) v |= ((cnt[p][k][l] >> j) & 1u) << l;
+                        if (v) atomicAdd(&acc[cgp[p] * 32 + j], v);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < cols; i += T) part[(size_t)k * cols + i] = acc[i];
+            __syncthreads();
+        }
     }
     if (exotic) my_err |= DEVERR_EXOTIC;
     if (my_err) atomicOr(a.err, my_err);
@@ -969,7 +1015,8 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
                 w = (int)std::max<uint64_t>(1, std::min<uint64_t>(w, (n_batches + ctx->n_cu - 1) / ctx->n_cu));
                 n_wg = (int)((n_batches + w - 1) / w);
             }
-            const size_t lds = (size_t)w * wave_lds + shared_lds;
+            // the flush of the kernels without QV planes adds the waves' counters up through LDS: [NC][w][kLevels][64] words
+            const size_t lds = std::max((size_t)w * wave_lds + shared_lds, (phase || np_kernel) ? (size_t)0 : (size_t)NC * w * kLevels * 256);
             a.partials = nullptr;
             if (!phase) {
                 // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
