@@ -86,9 +86,10 @@ def test_baked_phase_keys_and_partition(ctx, seed, W, thr):
     baked.close()
 
 
-def test_baked_synthetic_rich_set(ctx):
-    """The bench's QV workload shape: device-generated rich reads, all four thresholds."""
-    wl = synth.workload("pol_100k", n_reads=20000, rich_qv=True)
+@pytest.mark.parametrize("n", [20000, 1000000])
+def test_baked_synthetic_rich_set(ctx, n):
+    """The bench's QV workload shape (up to its full size): device-generated rich reads, all four thresholds."""
+    wl = synth.workload("pol_100k", n_reads=n, rich_qv=True)
     dr = device.synth_device(ctx, wl)
     q = abi.QvThresholds.make(60, 50, 42, 55)
     baked = device.bake_qv(ctx, dr, q)
