@@ -846,24 +846,35 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const uint32_t* __re
     codon += (size_t)col0 * 64;
     uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0, cod_sum = 0;
     int cod_idx = -1;
-    for (int wg = wg_lo + sub; wg < wg_hi; wg += 4) {
-        const uint32_t* p = partials + (size_t)wg * (NC + 1) * cols;
-        const uint32_t meta = p[(size_t)NC * cols + c];
-        const uint32_t m = p[c], g = p[(size_t)cols + c], cm = p[(size_t)2 * cols + c];
-        if (m) {  // m > 0 implies a valid guide base
+    // four workgroups' partials per trip, all their loads in flight together (the kernel is latency-bound)
+    for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += 16) {
+        uint32_t meta[4], m[4], g[4], cm[4], n4[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) base[k] += (meta & 3u) == (uint32_t)k ? m : 0u;
+        for (int u = 0; u < 4; ++u) {
+            const int wg = min(wg0 + 4 * u, wg_hi - 1);  // clamped: a slot past the end is loaded and ignored
+            const uint32_t* p = partials + (size_t)wg * (NC + 1) * cols;
+            meta[u] = p[(size_t)NC * cols + c];
+            m[u] = p[c];
+            g[u] = p[(size_t)cols + c];
+            cm[u] = p[(size_t)2 * cols + c];
+            n4[u] = NC > 3 ? p[(size_t)3 * cols + c] : 0u;
         }
-        gap += g;
-        if (NC > 3) nn += p[(size_t)3 * cols + c];
-        if (cm) {
-            const int idx = (int)((meta >> 8) & 63u);
-            if (idx != cod_idx) {
-                if (cod_sum) atomicAdd(&codon[(size_t)c * 64 + cod_idx], cod_sum);
-                cod_idx = idx;
-                cod_sum = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (wg0 + 4 * u >= wg_hi) break;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) base[k] += (meta[u] & 3u) == (uint32_t)k ? m[u] : 0u;  // m > 0 implies a valid guide base
+            gap += g[u];
+            nn += n4[u];
+            if (cm[u]) {
+                const int idx = (int)((meta[u] >> 8) & 63u);
+                if (idx != cod_idx) {
+                    if (cod_sum) atomicAdd(&codon[(size_t)c * 64 + cod_idx], cod_sum);
+                    cod_idx = idx;
+                    cod_sum = 0;
+                }
+                cod_sum += cm[u];
             }
-            cod_sum += cm;
         }
     }
 #pragma unroll
