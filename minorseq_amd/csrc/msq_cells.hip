@@ -2,8 +2,9 @@
 // AminoAcidCaller::CallVariants (src/AminoAcidCaller.cpp:86-103, 397-488) and Fisher::fisher_exact_tiss
 // (src/Fisher.cpp:12-143) on a host-built log-factorial table.
 //
-// One wavefront per codon position, one lane per codon (64 lanes == 64 codons): coverage, the number of
-// distinct codons and the majority codon are wave reductions; each lane then runs its own Fisher test.
+// One workgroup per codon position, one lane per codon (64 lanes == 64 codons): coverage, the number of
+// distinct codons and the majority codon are wave reductions; the position's cells are shared among the
+// workgroup's four waves, each Fisher sum spread over the 64 lanes of its wave.
 // FP64 throughout; compiled with -ffp-contract=off so every multiply/add/divide rounds exactly as the
 // reference's scalar code does.
 #include "msq_internal.h"
@@ -287,8 +288,11 @@ __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restri
                                                          msq_position* __restrict__ out_pos, double* __restrict__ out_p,
                                                          double* __restrict__ out_expected, uint32_t* __restrict__ err)
 {
-    const int lane = threadIdx.x & 63;
-    const int64_t p = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    // One workgroup per codon position; its four waves all work out the position's summary (cheap) and share the
+    // position's cells -- the Fisher sums are a serial chain per cell, and a grid of one wave per position leaves
+    // most SIMDs with nothing to overlap it with.
+    const int lane = threadIdx.x & 63, wsub = threadIdx.x >> 6, nsub = blockDim.x >> 6;
+    const int64_t p = blockIdx.x;
     if (p >= P) return;
     const int number_of_tests = *n_tests_raw;  // already 0 -> 1 (:102)
     const int gene = pos[p * 4 + 0], i = pos[p * 4 + 1], aa_pos = pos[p * 4 + 2], ref_from_seq = pos[p * 4 + 3];
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restri
         else
             ref = maj;
     }
-    if (lane == 0) {
+    if (lane == 0 && wsub == 0) {
         msq_position o;
         o.gene = gene; o.i = i; o.aa_pos = aa_pos; o.win_pos = win_pos; o.coverage = coverage;
         o.ref_codon = ref; o.alt_codon = alt; o.maj_codon = maj; o.maj_count = maj_count; o.skipped = skipped;
@@ -341,8 +345,10 @@ __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restri
     // every cell's point probability by its own lane (the table lookups of the position overlap), then the cells
     // one after the other, each summation spread over the wave's 64 lanes
     uint32_t e = 0;
-    const double base_p = cell ? d_hypergeom(lf, cnt, coverage - cnt, tc, td, &e) : 0.0;
-    unsigned long long todo = __ballot(cell);
+    const unsigned long long cells = __ballot(cell);
+    const bool mine = cell && (__popcll(cells & ((1ull << lane) - 1ull)) % nsub) == wsub;  // this wave's share
+    const double base_p = mine ? d_hypergeom(lf, cnt, coverage - cnt, tc, td, &e) : 0.0;
+    unsigned long long todo = __ballot(mine);
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -354,8 +360,8 @@ __global__ __launch_bounds__(256) void call_cells_kernel(const int32_t* __restri
         }
     }
     if (e) atomicOr(err, e);
-    out_p[p * 64 + lane] = pv;
-    if (out_expected) out_expected[p * 64 + lane] = expected;
+    if (mine || (!cell && wsub == 0)) out_p[p * 64 + lane] = pv;  // a cell by the wave that summed it, -1 by wave 0
+    if (out_expected && wsub == 0) out_expected[p * 64 + lane] = expected;
 }
 
 extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t* d_codon, const msq_error_model* em,
@@ -376,7 +382,7 @@ extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t
         int rc = msq_lfact_reserve(ctx, 4096);
         if (rc != MSQ_OK) return rc;
     }
-    const unsigned blocks = (unsigned)((plan->P + 3) / 4);
+    const unsigned blocks = (unsigned)plan->P;
     hipLaunchKernelGGL(count_tests_kernel, dim3((unsigned)((plan->P + 15) / 16)), dim3(1024), 0, ctx->stream, plan->d_pos, plan->P, plan->begin1,
                        plan->W, d_codon, ctx->d_small + 8, d_n_tests);
     MSQ_HIP(hipGetLastError());
