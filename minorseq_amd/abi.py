@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmsq_hip.so")
+# MSQ_LIB_DIR: an experiment build of the library (tools/exp_run.sh); the shipped one lives in lib/
+LIB_PATH = os.path.join(_HERE, os.environ.get("MSQ_LIB_DIR", "lib"), "libmsq_hip.so")
 
 MSQ_OK = 0
 MSQ_ERR_ARG, MSQ_ERR_HIP, MSQ_ERR_CIGAR, MSQ_ERR_BASE = -1, -2, -3, -4

@@ -53,6 +53,19 @@ extern "C" int msq_ctx_create(int device, msq_ctx** out)
     return MSQ_OK;
 }
 
+int msq_validate_reads(const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, const char* who)
+{
+    if (!d_reads->ref_start || !d_reads->group_off || !d_reads->bop) return msq_fail(MSQ_ERR_ARG, "%s: NULL read arrays", who);
+    if (((uintptr_t)d_reads->bop & 15u) != 0) return msq_fail(MSQ_ERR_ARG, "%s: bop must be 16-byte aligned", who);
+    if ((((uintptr_t)d_reads->qual | (uintptr_t)d_reads->delqv | (uintptr_t)d_reads->subqv | (uintptr_t)d_reads->insqv) & 15u) != 0)
+        return msq_fail(MSQ_ERR_ARG, "%s: QV planes must be 16-byte aligned", who);
+    for (int k = 0; k < 4; ++k) {
+        const int32_t t = (&thr->qual)[k];
+        if (t < -1 || t > 255) return msq_fail(MSQ_ERR_ARG, "%s: QV threshold %d out of range", who, t);
+    }
+    return MSQ_OK;
+}
+
 extern "C" int msq_ctx_destroy(msq_ctx* ctx)
 {
     if (!ctx) return MSQ_OK;

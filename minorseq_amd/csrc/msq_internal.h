@@ -65,3 +65,6 @@ int msq_fail(int code, const char* fmt, ...);
     } while (0)
 
 int msq_scratch(msq_ctx* ctx, size_t bytes, void** out);
+// The checks every entry point that streams packed reads shares: read arrays present, bit planes and QV planes
+// 16-byte aligned (the kernels load uint4), thresholds in -1..255 (qv_pass_mask's byte arithmetic).
+int msq_validate_reads(const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, const char* who);

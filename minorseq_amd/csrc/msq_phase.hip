@@ -57,7 +57,7 @@ extern "C" int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, c
     if (W < 0 || n_pos < 0) return msq_fail(MSQ_ERR_ARG, "msq_phase_codons: negative size");
     if (d_reads->n_reads == 0 || n_pos == 0) return MSQ_OK;
     if (!pos || !d_keys) return msq_fail(MSQ_ERR_ARG, "msq_phase_codons: NULL positions / keys");
-    if (!d_reads->ref_start || !d_reads->group_off || !d_reads->bop) return msq_fail(MSQ_ERR_ARG, "msq_phase_codons: NULL read arrays");
+    if (int rc = msq_validate_reads(d_reads, thr, "msq_phase_codons")) return rc;
     MSQ_HIP(hipSetDevice(ctx->device));
     {  // fast path: phase 1 of the streaming pileup kernel + a gather from its LDS rows
         bool handled = false;

@@ -193,14 +193,7 @@ extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const m
     if (W < 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup: negative window width %d", W);
     if (d_reads->n_reads == 0 || W == 0) return MSQ_OK;
     if (!d_nuc || !d_codon) return msq_fail(MSQ_ERR_ARG, "msq_pileup: NULL count matrix");
-    if (!d_reads->ref_start || !d_reads->group_off || !d_reads->bop) return msq_fail(MSQ_ERR_ARG, "msq_pileup: NULL read arrays");
-    if (((uintptr_t)d_reads->bop & 15u) != 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup: bop must be 16-byte aligned");
-    if ((((uintptr_t)d_reads->qual | (uintptr_t)d_reads->delqv | (uintptr_t)d_reads->subqv | (uintptr_t)d_reads->insqv) & 15u) != 0)
-        return msq_fail(MSQ_ERR_ARG, "msq_pileup: QV planes must be 16-byte aligned");
-    for (int k = 0; k < 4; ++k) {
-        const int32_t t = (&thr->qual)[k];
-        if (t < -1 || t > 255) return msq_fail(MSQ_ERR_ARG, "msq_pileup: QV threshold %d out of range", t);
-    }
+    if (int rc = msq_validate_reads(d_reads, thr, "msq_pileup")) return rc;
     MSQ_HIP(hipSetDevice(ctx->device));
     if (mode != MSQ_PILEUP_SIMPLE) {
         bool handled = false;
@@ -221,14 +214,7 @@ extern "C" int msq_pileup_device_window(msq_ctx* ctx, const msq_packed_reads* d_
     if (W_max < 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: negative capacity %d", W_max);
     if (d_reads->n_reads == 0 || W_max == 0) return MSQ_OK;
     if (!d_nuc || !d_codon) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: NULL count matrix");
-    if (!d_reads->ref_start || !d_reads->group_off || !d_reads->bop) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: NULL read arrays");
-    if (((uintptr_t)d_reads->bop & 15u) != 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: bop must be 16-byte aligned");
-    if ((((uintptr_t)d_reads->qual | (uintptr_t)d_reads->delqv | (uintptr_t)d_reads->subqv | (uintptr_t)d_reads->insqv) & 15u) != 0)
-        return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: QV planes must be 16-byte aligned");
-    for (int k = 0; k < 4; ++k) {
-        const int32_t t = (&thr->qual)[k];
-        if (t < -1 || t > 255) return msq_fail(MSQ_ERR_ARG, "msq_pileup_device_window: QV threshold %d out of range", t);
-    }
+    if (int rc = msq_validate_reads(d_reads, thr, "msq_pileup_device_window")) return rc;
     MSQ_HIP(hipSetDevice(ctx->device));
     bool handled = false;
     int rc = msq_pileup_stream_launch(ctx, *d_reads, *thr, begin0, W_max, d_bounds, d_nuc, d_codon, &handled);

@@ -386,6 +386,14 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     constexpr bool COUNT_N = MANY_N;
     constexpr int NC = COUNT_N ? 4 : 3;
     extern __shared__ __align__(16) uint32_t lds[];
+#ifdef MSQ_TRACE  // timing experiment: phase timestamps (100 MHz) of a few waves, printed at the end
+    uint64_t tr_[8];
+    int tr_n = 0;
+#define MSQ_TR() (tr_[tr_n++] = wall_clock64())
+#else
+#define MSQ_TR() ((void)0)
+#endif
+    MSQ_TR();
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, NWV = T >> 6;
     const int wave = (int)uni((uint32_t)tid >> 6);   // tell the compiler it is wave-uniform: all stream control is scalar
     const int RD = a.RD, G = a.G;
@@ -712,7 +720,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     // the only workgroup barriers before the flush: a wave without reads meets them too), and only then do the
     // counters come to life, so nothing but the load slots is live across the call.
     bool have = cs.live;
+    MSQ_TR();
     if (have) chunks();
+    MSQ_TR();
     if (!PHASE) {
         learn_guide();
 #pragma unroll
@@ -722,6 +732,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
 #pragma unroll
                 for (int l = 0; l < kLevels; ++l) cnt[p][k][l] = 0;
     }
+    MSQ_TR();
     while (have) {  // a wave batch is complete in the rows
         if (PHASE) {
             gather();
@@ -752,7 +763,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     // ---- flush: per column the guide's nucleotide / codon bins (meta); then the waves' bit-sliced counters are added
     // up while still bit-sliced (two bitop3 per level and counter, against some sixty instructions per counter to
     // transpose it), one wave per counter, and only the sum is transposed and stored as this workgroup's partial
+    MSQ_TR();
     __syncthreads();
+    MSQ_TR();
     const int cols = G * 32;
     uint32_t* const part = a.partials + (size_t)blockIdx.x * (NC + 1) * cols;
     auto gbit = [&](int plane, int c) -> uint32_t { return (gl[(c >> 5) * 4 + plane] >> (c & 31)) & 1u; };
@@ -829,6 +842,14 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     }
     if (exotic) my_err |= DEVERR_EXOTIC;
     if (my_err) atomicOr(a.err, my_err);
+#ifdef MSQ_TRACE
+    MSQ_TR();
+    if (lane == 0 && (wave == 0 || wave == NWV - 1) && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == gridDim.x - 1))
+        printf("trace wg %3d wave %d: start %llu | init %4llu first-batch %4llu guide %4llu loop %5llu wait %4llu flush %4llu (x10 ns)\n", (int)blockIdx.x, wave,
+               (unsigned long long)tr_[0], (unsigned long long)(tr_[1] - tr_[0]), (unsigned long long)(tr_[2] - tr_[1]),
+               (unsigned long long)(tr_[3] - tr_[2]), (unsigned long long)(tr_[4] - tr_[3]), (unsigned long long)(tr_[5] - tr_[4]),
+               (unsigned long long)(tr_[6] - tr_[5]));
+#endif
 }
 
 // Fold the workgroup partials into the count matrices: matches go to each workgroup's guide nucleotide / codon
