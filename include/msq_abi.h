@@ -213,6 +213,17 @@ int msq_partition_free(msq_ctx* ctx, msq_partition* p);
 /* msq_pileup over the partition's window: slab after slab, each over its own read set.  Async. */
 int msq_pileup_partition(msq_ctx* ctx, const msq_partition* p, const msq_qv_thresholds* thr, uint32_t* d_nuc,
                          uint32_t* d_codon);
+/* msq_pileup for callers that must not allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same result as msq_pileup(..., MSQ_PILEUP_STREAM), added into
+ * the caller's matrices, but the one buffer the pileup needs beyond its inputs and outputs -- the per-workgroup
+ * partial counts -- lives in a device array built into the library (20 MiB per GPU, held until the process ends)
+ * instead of the context's scratch, and the call makes no hipMalloc / hipFree.  Limits: W <= 4096 columns (one
+ * column slab), GPUs of up to 256 CUs, reads without MSQ_READS_HAS_EXOTIC; anything beyond is refused with
+ * MSQ_ERR_ARG.  All calls on one GPU share that array: calls that overlap on one GPU (two contexts or two streams)
+ * race -- serialise them.  Nothing in it has to be cleared between calls (every launch overwrites the partials it
+ * then folds).  Async on the context's stream; deferred errors through msq_pileup_check as for msq_pileup. */
+int msq_pileup_noalloc(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
+                       int32_t W, uint32_t* d_nuc, uint32_t* d_codon);
 /* Deferred device-side error of the pileups enqueued since the last check (MSQ_ERR_BASE / MSQ_ERR_WINDOW).
  * Synchronises. */
 int msq_pileup_check(msq_ctx* ctx);

@@ -111,6 +111,7 @@ _SIGNATURES = {
     "msq_partition_free": (C.c_int, [_P, _P]),
     "msq_pileup_partition": (C.c_int, [_P, _P, C.POINTER(QvThresholds), _P, _P]),
     "msq_pileup": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P, C.c_int]),
+    "msq_pileup_noalloc": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P]),
     "msq_pileup_check": (C.c_int, [_P]),
     "msq_phase_codons": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "msq_timing_enable": (C.c_int, [_P, C.c_int32]),

@@ -49,6 +49,11 @@ extern "C" int msq_ctx_create(int device, msq_ctx** out)
         delete c;
         return msq_fail(MSQ_ERR_HIP, "msq_ctx_create: %s", hipGetErrorString(e));
     }
+    if (int rc = msq_noalloc_init(c)) {  // this GPU's address of the built-in scratch (msq_pileup_noalloc)
+        (void)hipFree(c->d_err);
+        delete c;
+        return rc;
+    }
     *out = c;
     return MSQ_OK;
 }

@@ -37,6 +37,9 @@ struct msq_ctx {
     void* h_stage[2] = {nullptr, nullptr};
     size_t h_stage_bytes = 0;
     hipEvent_t stage_done[2] = {nullptr, nullptr};
+    // msq_pileup_noalloc: this GPU's copy of the built-in scratch array (resolved once, at context creation)
+    uint32_t* d_noalloc = nullptr;
+    size_t noalloc_bytes = 0;
     // measurement aid: event pairs around the dominant pileup kernel (msq_timing_enable)
     std::vector<hipEvent_t> ev_begin, ev_end;
     int ev_used = 0;
@@ -65,6 +68,7 @@ int msq_fail(int code, const char* fmt, ...);
     } while (0)
 
 int msq_scratch(msq_ctx* ctx, size_t bytes, void** out);
+int msq_noalloc_init(msq_ctx* ctx);
 // The checks every entry point that streams packed reads shares: read arrays present, bit planes and QV planes
 // 16-byte aligned (the kernels load uint4), thresholds in -1..255 (qv_pass_mask's byte arithmetic).
 int msq_validate_reads(const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, const char* who);

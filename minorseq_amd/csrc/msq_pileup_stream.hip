@@ -944,9 +944,11 @@ void msq_slab_layout(int32_t W, int max_words, int* n_slabs, int* Gslab)
     *Gslab = *n_slabs ? (Gtot + *n_slabs - 1) / *n_slabs : 0;
 }
 
+// fixed_partials: NULL, or a caller-provided buffer of fixed_bytes for the workgroup partials (msq_pileup_noalloc:
+// nothing is allocated then, and a launch that needs more is refused).
 static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
                          const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon, const PhaseRequest* phase, bool* handled,
-                         int only_slab = -1, int slab_words = 128)
+                         int only_slab = -1, int slab_words = 128, uint32_t* fixed_partials = nullptr, size_t fixed_bytes = 0)
 {
     *handled = false;
     if (R.flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
@@ -1052,9 +1054,15 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
             a.partials = nullptr;
             if (!phase) {
                 // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
-                void* s = nullptr;
-                int rc = msq_scratch(ctx, (size_t)ctx->n_cu * (NC + 1) * Gslab * 32 * 4, &s);
-                if (rc != MSQ_OK) return rc;
+                const size_t need = (size_t)ctx->n_cu * (NC + 1) * Gslab * 32 * 4;
+                void* s = fixed_partials;
+                if (fixed_partials) {
+                    if (need > fixed_bytes)
+                        return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: %zu bytes of workgroup partials exceed the built-in %zu", need, fixed_bytes);
+                } else {
+                    int rc = msq_scratch(ctx, need, &s);
+                    if (rc != MSQ_OK) return rc;
+                }
                 a.partials = (uint32_t*)s;
             }
             a.read_lo = lo;
@@ -1090,6 +1098,49 @@ int msq_pileup_stream_slab_launch(msq_ctx* ctx, const msq_packed_reads& R, const
                                   int32_t W, int slab, int slab_words, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
 {
     return stream_launch(ctx, R, thr, win_begin0, W, nullptr, d_nuc, d_codon, nullptr, handled, slab, slab_words);
+}
+
+// ------------------------------------------------------------------------------------------ no-allocation door
+// msq_pileup_noalloc: msq_pileup's streaming path with the workgroup partials -- the one buffer the pileup needs
+// beyond its inputs and outputs -- in a file-scope device array instead of the context's grown-on-demand scratch.
+// One copy of the array exists per GPU; its address on a GPU is asked for once, with that GPU current
+// (msq_noalloc_init, from msq_ctx_create), and kept in the context.  Only that pointer ever reaches a kernel or a
+// runtime call: `scratch` itself is a host-side handle here, not a device address.
+constexpr int kNoallocMaxColumns = 4096;  // one column slab
+constexpr int kNoallocMaxCU = 256;
+constexpr size_t kNoallocWords = (size_t)kNoallocMaxCU * 5 * kNoallocMaxColumns;  // [n_cu][NC + 1 <= 5][columns] u32 = 20 MiB
+static __device__ __align__(256) uint32_t scratch[kNoallocWords];
+
+int msq_noalloc_init(msq_ctx* ctx)  // the context's device is current
+{
+    void* p = nullptr;
+    MSQ_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    ctx->d_noalloc = static_cast<uint32_t*>(p);
+    ctx->noalloc_bytes = sizeof(uint32_t) * kNoallocWords;
+    return MSQ_OK;
+}
+
+extern "C" int msq_pileup_noalloc(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
+                                  int32_t W, uint32_t* d_nuc, uint32_t* d_codon)
+{
+    if (!ctx || !d_reads || !thr) return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: NULL argument");
+    if (W < 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: negative window width %d", W);
+    if (W > kNoallocMaxColumns)
+        return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: window of %d columns exceeds the maximum of %d (use msq_pileup)", W, kNoallocMaxColumns);
+    if (d_reads->n_reads == 0 || W == 0) return MSQ_OK;
+    int rc = msq_validate_reads(d_reads, thr, "msq_pileup_noalloc");
+    if (rc != MSQ_OK) return rc;
+    if (!d_nuc || !d_codon) return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: NULL count matrix");
+    if (d_reads->flags & MSQ_READS_HAS_EXOTIC)
+        return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: reads with exotic symbols need msq_pileup (flags=%u)", d_reads->flags);
+    if (!ctx->d_noalloc) return msq_fail(MSQ_ERR_HIP, "msq_pileup_noalloc: the built-in scratch was not resolved at context creation");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    bool handled = false;
+    rc = stream_launch(ctx, *d_reads, *thr, win_begin0, W, nullptr, d_nuc, d_codon, nullptr, &handled, -1, 128, ctx->d_noalloc,
+                       ctx->noalloc_bytes);
+    if (rc != MSQ_OK) return rc;
+    if (!handled) return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: streaming kernel not applicable (flags=%u)", d_reads->flags);
+    return MSQ_OK;
 }
 
 int msq_phase_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
