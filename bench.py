@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- juliet pileup + Fisher hot path on MI355X: aligned CCS reads/s and % of the HBM roofline.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pol_1m] [--reads R]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload pol_1m] [--reads R] [--scaling weak|strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one pass of the hot path over one batch of synthetic reads already resident in HBM:
-window bounds -> zero the count matrices -> pileup (nucleotide + codon counts) -> [N > 1: RCCL all-reduce of the
-integer count matrices] -> CountNumberOfTests + per-(position, codon) Fisher cells.  By default the window bounds
-stay in HBM between the bounds kernel and the pileup (msq_window_bounds_device / msq_pileup_device_window: the
-count matrices are sized from the set-up window, a wider window would raise a deferred error, and the bounds are
-compared with the set-up window after the timed loop); --host-bounds brings them back to the host every step, as
-MSAByRow's constructor does.  N > 1 is weak scaling:
-every rank holds its own shard of `reads` reads of one global sample (global read index = rank * reads + i),
-there is no data-path collective besides the count all-reduce the north star prescribes.
+
+  window bounds of the shard + cleared count matrices (one launch, msq_pileup_begin)
+  -> pileup of the shard inside the sample's window (nucleotide + codon counts; stream kernel + fold)
+  -> [N > 1: ONE RCCL group over xGMI -- MAX of the bounds, u32 SUM of the count matrices; the library's own
+     communicator, msq_comm_*]
+  -> CountNumberOfTests + per-(position, codon) Fisher cells, replicated on every rank.
+
+The window is known from the set-up (as from juliet's --region); the bounds are still recomputed from the reads in
+every step and compared with it after the timed loop.  --window device discovers the window on the device in every
+step instead (bounds -> [MAX all-reduce] -> pileup reads its window from HBM -> [SUM all-reduce]); --window host
+brings it back to the host every step, as MSAByRow's constructor does.
+
+N > 1: every rank holds a shard of one global sample.  "weak" (the line's `value`): `reads` reads per GPU, global
+read index = rank * reads + i.  "strong": the workload's reads split over the ranks ([r N / P, (r + 1) N / P)), as
+BASELINE config #3 states it; with N > 1 the weak line also carries the strong measurement of the same run as
+`strong_scaling`, and --scaling strong makes it the line's `value`.
 
 Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the read-streaming pileup kernel) timed with
-HIP events on its own stream inside the timed region; `cpu_baseline` is the oracle (CPU restatement of the
-reference path) on a bounded sample, rank 0 at N = 1 only.
+HIP events on its own stream inside the timed region (every --time-every-th step: an event pair costs the stream
+~10 us of bubbles); `cpu_baseline` is the oracle (CPU restatement of the reference path) on a bounded sample,
+rank 0 at N = 1 only.
 """
 import argparse
 import ctypes as C
@@ -38,27 +47,53 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pol_1m", help="pol_1m (default: 1M x 2843, north-star target), pol_100k, "
                     "hiv_mix_200k, amp20k_10m")
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: the workload's)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (weak) / of the sample (strong); default: the workload's")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--qualqv", type=int, default=-1, help="QUALQV threshold (env var of the reference); -1 = unset")
     ap.add_argument("--rich", action="store_true", help="reads carry DelQV / SubQV / InsQV as well (4.5 B/base) and the "
                     "reference's default SUBQV=42 applies (src/QvThresholds.cpp:45-56)")
     ap.add_argument("--no-bake", action="store_true", help="with --qualqv: keep the QV plane and apply the threshold "
                     "inside every pileup pass instead of once at set-up (msq_reads_bake_qv)")
     ap.add_argument("--mode", default="auto", choices=["auto", "simple", "stream"])
-    ap.add_argument("--host-bounds", action="store_true", help="bring the window bounds back to the host every step "
-                    "(msq_window_bounds + msq_pileup) instead of leaving them in HBM (msq_window_bounds_device + "
-                    "msq_pileup_device_window, the default)")
+    ap.add_argument("--window", default="known", choices=["known", "device", "host"], help="see the module docstring")
+    ap.add_argument("--host-bounds", action="store_true", help="= --window host")
     ap.add_argument("--no-partition", action="store_true", help="windows wider than 4096 columns: run every slab launch "
                     "over the whole read set instead of over the column-slab partition built at set-up")
     ap.add_argument("--slab-columns", type=int, default=0, help="widest column slab of the partition (multiple of 32, "
                     "<= 4096); narrower than the window: partition even a window that fits one slab")
-    ap.add_argument("--force-dist", action="store_true", help="rehearsal: initialise the RCCL process group and issue "
-                    "the step's collectives even with one rank")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: create the library's RCCL communicator and "
+                    "issue the step's collectives even with one rank")
+    ap.add_argument("--time-every", type=int, default=4, help="HIP events around the pileup kernel in every n-th step")
+    ap.add_argument("--verify", action="store_true", help="after the timed loop: the count matrices of the last step "
+                    "against the independent simple kernel's (bit for bit)")
+    # data dependence of the pileup kernel: how far the sample strays from its majority sequence
+    ap.add_argument("--n-minors", type=int, default=-1, help="minor clones in the sample (default: the workload's 2)")
+    ap.add_argument("--minor-frac", type=float, default=-1.0, help="share of the reads in EACH minor clone (default 0.01)")
+    ap.add_argument("--minor-codons", type=int, default=-1, help="codons in which a minor clone differs (default 10)")
+    ap.add_argument("--sub-rate", type=float, default=-1.0, help="substitution errors per base (default 0.0005244257)")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)  # name:first:n -> prints the oracle's seconds
     ap.add_argument("--h2d-steps", type=int, default=0, help="also time K steps that first copy the packed reads from "
                     "pinned host memory (PCIe-inclusive rate, reported beside `value`, never as it)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.host_bounds:
+        a.window = "host"
+    return a
+
+
+def workload_kwargs(a):
+    kw = {}
+    if a.rich:
+        kw["rich_qv"] = True
+    if a.n_minors >= 0:
+        kw["n_minors"] = a.n_minors
+    if a.minor_frac >= 0:
+        kw["minor_frac"] = a.minor_frac
+    if a.minor_codons >= 0:
+        kw["minor_codons"] = a.minor_codons
+    if a.sub_rate >= 0:
+        kw["sub"] = a.sub_rate
+    return kw
 
 
 def load_traffic(kernel, workload, reads, qualqv, baked=False):
@@ -117,6 +152,138 @@ def cpu_baseline(name, sample):
                           "sample": "%d processes x %d reads, slowest %.1f s" % (procs, per, max(dts))}}
 
 
+class Run:
+    """One shard resident in HBM with everything a step needs, and the timed loop over it."""
+
+    def __init__(self, a, ctx, ex, wl, first, reads, global_reads, window):
+        import torch
+        from minorseq_amd import abi, device
+        self.a, self.ctx, self.ex, self.wl, self.reads = a, ctx, ex, wl, reads
+        self.torch, self.abi, self.device = torch, abi, device
+        L = self.L = abi.lib()
+        self.thr = abi.QvThresholds.make(qual=a.qualqv, sub=42 if a.rich else -1)
+        self.mode = {"auto": abi.MSQ_PILEUP_AUTO, "simple": abi.MSQ_PILEUP_SIMPLE, "stream": abi.MSQ_PILEUP_STREAM}[a.mode]
+        # ---- setup (untimed): reads into HBM, plan, log-factorial table
+        dr = device.synth_device(ctx, wl, first, reads)
+        self.n_bases = dr.n_groups * 32
+        # a run's QV thresholds are fixed before the reads are loaded: they are applied once, at pack time (untimed like
+        # the packing itself), and the passes below stream the baked set -- as the front does (MSAByRow::Finish)
+        self.baked = (a.qualqv >= 0 or a.rich) and not a.no_bake and a.h2d_steps == 0
+        if self.baked:
+            src = dr
+            dr = device.bake_qv(ctx, src, self.thr)
+            ctx.sync()
+            del src
+        self.dr = dr
+        if window is None:
+            window = ex.allreduce_bounds(*device.window_bounds(ctx, dr))
+        self.b0, self.e0 = window
+        b0, W = self.b0, self.e0 - self.b0
+        self.W = W
+        gb, ge = wl.gene_arrays()
+        self.plan = device.Plan(ctx, gb, ge, wl.reference if wl.use_reference else "", b0 + 1, W)
+        ctx.lfact_reserve(2 * global_reads + 2)
+        self.counts = torch.zeros(W * 70, dtype=torch.int32, device="cuda")  # [W][6] nucleotide then [W][64] codon, one buffer
+        self.nuc, self.codon = self.counts[:W * 6], self.counts[W * 6:]
+        self.em = abi.ErrorModel()
+        abi.check(L.msq_error_model_default(C.byref(self.em)))
+        self.bounds = torch.zeros(2, dtype=torch.int32, device="cuda")  # {-begin0, end0}, device-resident
+        # windows wider than one slab of the streaming kernel: the reads are laid out per column slab at set-up (pack
+        # time, untimed like the packing itself), so that every slab launch streams only its share of the reads
+        self.part = None
+        if (W > 4096 or 0 < a.slab_columns < W) and not a.no_partition and a.mode != "simple":
+            self.part = device.Partition(ctx, dr, b0, W, a.slab_columns)
+        self.launches_per_step = self.part.n_slabs if self.part else 1  # timing slots: one per pileup call that reaches the kernel
+        self.flow = "host" if (a.window == "host" or (a.mode == "simple" and a.window == "device")) else a.window
+        if self.part and self.flow == "device":
+            self.flow = "known"  # a partition is laid out for its window
+
+    def cells(self):
+        p = self.plan
+        self.abi.check(self.L.msq_call_cells(self.ctx.h, p.h, self.codon.data_ptr(), C.byref(self.em), 100.0, p.positions.data_ptr(),
+                                             p.p.data_ptr(), p.expected.data_ptr(), p.n_tests.data_ptr()))
+
+    def step(self):
+        L, abi, ctx, dr, ex = self.L, self.abi, self.ctx, self.dr, self.ex
+        if self.flow == "known":
+            # bounds of the shard + cleared matrices in one launch; the pileup inside the sample's window; one RCCL group
+            abi.check(L.msq_pileup_begin(ctx.h, dr.view, self.bounds.data_ptr(), self.counts.data_ptr(), self.counts.numel()))
+            if self.part:
+                abi.check(L.msq_pileup_partition(ctx.h, self.part._h, self.thr, self.nuc.data_ptr(), self.codon.data_ptr()))
+            else:
+                abi.check(L.msq_pileup(ctx.h, dr.view, self.thr, self.b0, self.W, self.nuc.data_ptr(), self.codon.data_ptr(), self.mode))
+            ex.allreduce_step(self.bounds, self.counts)
+        elif self.flow == "device":  # the window discovered on the device: nothing in the step waits for the host
+            abi.check(L.msq_window_bounds_device(ctx.h, dr.view, self.bounds.data_ptr()))
+            ex.allreduce_bounds_device(self.bounds)  # N > 1: one 2-int MAX
+            self.counts.zero_()
+            abi.check(L.msq_pileup_device_window(ctx.h, dr.view, self.thr, self.bounds.data_ptr(), self.b0, self.W, self.nuc.data_ptr(),
+                                                 self.codon.data_ptr()))
+            ex.allreduce_counts(self.counts)
+        else:  # the window comes back to the host every step, as MSAByRow's constructor needs it
+            w = ex.allreduce_bounds(*self.device.window_bounds(ctx, dr))  # MSAByRow pass 1 (UpdateBoundaries)
+            self.bounds.copy_(self.torch.tensor([-w[0], w[1]], dtype=self.torch.int32))
+            self.counts.zero_()
+            if self.part:
+                abi.check(L.msq_pileup_partition(ctx.h, self.part._h, self.thr, self.nuc.data_ptr(), self.codon.data_ptr()))
+            else:
+                abi.check(L.msq_pileup(ctx.h, dr.view, self.thr, self.b0, self.W, self.nuc.data_ptr(), self.codon.data_ptr(), self.mode))
+            ex.allreduce_counts(self.counts)
+        self.cells()
+
+    def timed(self, barrier):
+        a, abi, L, ctx = self.a, self.abi, self.L, self.ctx
+        for _ in range(a.warmup):
+            self.step()
+        abi.check(L.msq_pileup_check(ctx.h))
+        abi.check(L.msq_call_check(ctx.h))
+        stride = 1 if self.launches_per_step > 1 else max(1, min(a.time_every, a.steps))
+        n_slots = (a.steps * self.launches_per_step + stride - 1) // stride
+        abi.check(L.msq_timing_enable_strided(ctx.h, n_slots, stride))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            self.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        abi.check(L.msq_pileup_check(ctx.h))
+        abi.check(L.msq_call_check(ctx.h))
+        if self.bounds.tolist() != [-self.b0, self.e0]:
+            raise SystemExit("window bounds of the timed steps %s differ from the set-up window [%d, %d)" % (self.bounds.tolist(), self.b0, self.e0))
+        ms = (C.c_float * n_slots)()
+        n_ms = C.c_int32(0)
+        path_ms = None
+        if self.launches_per_step == 1:
+            abi.check(L.msq_timing_read_path(ctx.h, ms, n_slots, C.byref(n_ms)))
+            path_ms = sum(ms[:n_ms.value]) / max(1, n_ms.value)
+        abi.check(L.msq_timing_read(ctx.h, ms, n_slots, C.byref(n_ms)))
+        abi.check(L.msq_timing_enable(ctx.h, 0))
+        timed_steps = max(1, n_ms.value // self.launches_per_step)
+        kernel_ms = sum(ms[:n_ms.value]) / timed_steps  # per step: the slab launches of a partition added up
+        return dt, kernel_ms, path_ms, timed_steps
+
+    def verify(self):
+        """The count matrices the last step left against the simple kernel's on the same shard (+ the same exchange)."""
+        torch, abi = self.torch, self.abi
+        ref = torch.zeros_like(self.counts)
+        W = self.W
+        abi.check(self.L.msq_pileup(self.ctx.h, self.dr.view, self.thr, self.b0, W, ref[:W * 6].data_ptr(), ref[W * 6:].data_ptr(),
+                                    abi.MSQ_PILEUP_SIMPLE))
+        abi.check(self.L.msq_pileup_check(self.ctx.h))
+        self.ex.allreduce_counts(ref)
+        if not torch.equal(ref, self.counts):
+            bad = int((ref != self.counts).sum())
+            raise SystemExit("--verify: %d of %d count-matrix entries differ from the simple kernel's" % (bad, ref.numel()))
+        return True
+
+    def deviation_share(self):
+        """Share of the piled-up ACGT bases that differ from their column's majority base: what the stream kernel
+        sends down its per-base atomic path instead of its bit-sliced counters."""
+        n = self.nuc.view(-1, 6)[:, :4].to(self.torch.int64)
+        tot = int(n.sum())
+        return 1.0 - int(n.max(1).values.sum()) / max(1, tot)
+
+
 def main():
     a = parse()
     if a.cpu_worker:
@@ -127,9 +294,14 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.cpu_sample > 0:
         from minorseq_amd import synth as _synth
         cpu = cpu_baseline(a.workload, min(a.cpu_sample, a.reads or _synth.workload(a.workload).n_reads))
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print while the run is set up (RCCL's
+    # version banner, for one) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
-    from minorseq_amd import abi, device, sharding, synth
+    from minorseq_amd import device, sharding, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,123 +311,81 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
-    if world > 1 or a.force_dist:
+    ctx = device.Ctx(local)
+    multi = world > 1 or a.force_dist
+    if multi:
+        # control plane only (the communicator id, the barrier, the max-over-ranks clock): gloo over loopback; the
+        # data path is the library's RCCL communicator on the context's stream
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        sharding.FORCE_COLLECTIVES = a.force_dist
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ex = sharding.LibExchange(ctx, rank, world, sharding.torch_bootstrap)
+    else:
+        ex = sharding.NoExchange()
 
-    wl = synth.workload(a.workload, rich_qv=True) if a.rich else synth.workload(a.workload)
+    wl = synth.workload(a.workload, **workload_kwargs(a))
     reads = a.reads or wl.n_reads
-    ctx = device.Ctx(local)
-    L = abi.lib()
-    thr = abi.QvThresholds.make(qual=a.qualqv, sub=42 if a.rich else -1)
-    mode = {"auto": abi.MSQ_PILEUP_AUTO, "simple": abi.MSQ_PILEUP_SIMPLE, "stream": abi.MSQ_PILEUP_STREAM}[a.mode]
-
-    # ---- setup (untimed): reads into HBM, plan, log-factorial table
-    dr = device.synth_device(ctx, wl, rank * reads, reads)
-    n_bases = dr.n_groups * 32
-    # a run's QV thresholds are fixed before the reads are loaded: they are applied once, at pack time (untimed like
-    # the packing itself), and the passes below stream the baked set -- as the front does (MSAByRow::Finish)
-    baked = (a.qualqv >= 0 or a.rich) and not a.no_bake and a.h2d_steps == 0
-    if baked:
-        src = dr
-        dr = device.bake_qv(ctx, src, thr)
-        ctx.sync()
-        del src
-    b0, e0 = sharding.allreduce_bounds(*device.window_bounds(ctx, dr), "cuda")
-    W = e0 - b0
-    gb, ge = wl.gene_arrays()
-    plan = device.Plan(ctx, gb, ge, wl.reference if wl.use_reference else "", b0 + 1, W)
-    ctx.lfact_reserve(2 * reads * world + 2)
-    counts = torch.zeros(W * 70, dtype=torch.int32, device="cuda")  # [W][6] nucleotide then [W][64] codon, one buffer
-    nuc, codon = counts[:W * 6], counts[W * 6:]
-    em = abi.ErrorModel()
-    abi.check(L.msq_error_model_default(C.byref(em)))
-
-    bounds = torch.zeros(2, dtype=torch.int32, device="cuda")  # {-begin0, end0}, device-resident
-
-    def step_host_bounds():  # the window comes back to the host every step, as MSAByRow's constructor needs it
-        sharding.allreduce_bounds(*device.window_bounds(ctx, dr), "cuda")  # MSAByRow pass 1 (UpdateBoundaries)
-        counts.zero_()
-        abi.check(L.msq_pileup(ctx.h, dr.view, thr, b0, W, nuc.data_ptr(), codon.data_ptr(), mode))
-        sharding.allreduce_counts(counts)  # N > 1: RCCL sum of the integer count matrices over xGMI
-        abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
-                                   plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))
-
-    def step_device_bounds():  # the same work with the window left in HBM: nothing in the step waits for the host
-        abi.check(L.msq_window_bounds_device(ctx.h, dr.view, bounds.data_ptr()))
-        sharding.allreduce_bounds_device(bounds)  # N > 1: one 2-int MAX
-        counts.zero_()
-        abi.check(L.msq_pileup_device_window(ctx.h, dr.view, thr, bounds.data_ptr(), b0, W, nuc.data_ptr(), codon.data_ptr()))
-        sharding.allreduce_counts(counts)
-        abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
-                                   plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))
-
-    # windows wider than one slab of the streaming kernel: the reads are laid out per column slab at set-up (pack
-    # time, untimed like the packing itself), so that every slab launch streams only its share of the reads
-    part = None
-    if (W > 4096 or 0 < a.slab_columns < W) and not a.no_partition and a.mode != "simple":
-        part = device.Partition(ctx, dr, b0, W, a.slab_columns)
-
-    def step_partition():
-        abi.check(L.msq_window_bounds_device(ctx.h, dr.view, bounds.data_ptr()))
-        sharding.allreduce_bounds_device(bounds)
-        counts.zero_()
-        abi.check(L.msq_pileup_partition(ctx.h, part._h, thr, nuc.data_ptr(), codon.data_ptr()))
-        sharding.allreduce_counts(counts)
-        abi.check(L.msq_call_cells(ctx.h, plan.h, codon.data_ptr(), C.byref(em), 100.0, plan.positions.data_ptr(),
-                                   plan.p.data_ptr(), plan.expected.data_ptr(), plan.n_tests.data_ptr()))
-
-    step = step_partition if part else step_host_bounds if (a.host_bounds or a.mode == "simple") else step_device_bounds
-    launches_per_step = part.n_slabs if part else 1  # timing slots: one per pileup call that reaches the kernel
 
     def barrier():
-        if world > 1 or a.force_dist:
+        torch.cuda.synchronize()
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    abi.check(L.msq_pileup_check(ctx.h))
-    abi.check(L.msq_call_check(ctx.h))
-    abi.check(L.msq_timing_enable(ctx.h, a.steps * launches_per_step))
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    abi.check(L.msq_pileup_check(ctx.h))
-    abi.check(L.msq_call_check(ctx.h))
-    if step is not step_host_bounds and bounds.tolist() != [-b0, e0]:
-        raise SystemExit("device-resident window bounds %s differ from the set-up window [%d, %d)" % (bounds.tolist(), b0, e0))
-    n_slots = a.steps * launches_per_step
-    ms = (C.c_float * n_slots)()
-    n_ms = C.c_int32(0)
-    abi.check(L.msq_timing_read(ctx.h, ms, n_slots, C.byref(n_ms)))
-    abi.check(L.msq_timing_enable(ctx.h, 0))
-    kernel_ms = sum(ms[:n_ms.value]) / max(1, a.steps)  # per step: the slab launches of a partition added up
+    def max_over_ranks(x):
+        if not multi:
+            return x
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def measure(scaling):
+        if scaling == "weak":
+            first, n, total = rank * reads, reads, reads * world
+        else:
+            first, n = sharding.shard_range(reads, rank, world)
+            total = reads
+        run = Run(a, ctx, ex, wl, first, n, total, None)
+        dt, kernel_ms, path_ms, timed_steps = run.timed(barrier)
+        dt = max_over_ranks(dt)
+        verified = run.verify() if a.verify else None
+        return run, total, dt, kernel_ms, path_ms, timed_steps, verified
+
+    primary = measure(a.scaling)
+    run, total, dt, kernel_ms, path_ms, timed_steps, verified = primary
+    secondary = None
+    if world > 1 and a.scaling == "weak":  # the strong-scaling measurement of the same run, carried along
+        keep = (run.n_bases, run.W, run.plan.P, int(run.plan.n_tests.item()), run.baked, run.flow, run.part.n_slabs if run.part else None,
+                run.deviation_share(), run.reads)
+        del run, primary
+        torch.cuda.empty_cache()
+        s_run, s_total, s_dt, s_kernel_ms, s_path_ms, _, _ = measure("strong")
+        secondary = {"value": s_total / (s_dt / a.steps), "unit": "reads/s", "ms_per_step": s_dt / a.steps * 1e3,
+                     "reads_per_gpu": s_run.reads, "kernel_ms": s_kernel_ms, "path_ms": s_path_ms,
+                     "sample": "%d reads of %s split over %d GPUs" % (s_total, wl.name, world)}
+        n_bases, W, P, n_tests, baked, flow, n_slabs, dev_share, shard_reads = keep
+    else:
+        n_bases, W, P, n_tests, baked, flow, n_slabs, dev_share, shard_reads = (
+            run.n_bases, run.W, run.plan.P, int(run.plan.n_tests.item()), run.baked, run.flow, run.part.n_slabs if run.part else None,
+            run.deviation_share(), run.reads)
 
     pcie = None
     if a.h2d_steps > 0 and world == 1:  # the boundary handing over host buffers: packed reads cross PCIe every step
+        dr = run.dr
         host = {f: t.cpu().pin_memory() for f, t in dr.t.items() if t is not None}
         barrier()
         t1 = time.perf_counter()
         for _ in range(a.h2d_steps):
             for f, h in host.items():
                 dr.t[f].copy_(h, non_blocking=True)
-            step()
+            run.step()
         barrier()
         dt1 = (time.perf_counter() - t1) / a.h2d_steps
         pcie = {"value": reads / dt1, "unit": "reads/s", "ms_per_step": dt1 * 1e3,
                 "host_bytes_per_step": int(sum(h.numel() * h.element_size() for h in host.values()))}
         del host
 
-    if world > 1 or a.force_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         # N * (1.001 * W * 1.5 + 12) -- bit planes + one QV byte per base.  Rich reads are priced by the QV
@@ -263,40 +393,62 @@ def main():
         # the QualQV-only case.
         planes = (1 if a.qualqv >= 0 else 0) + (1 if a.rich else 0)
         per_base = 1.5 if (baked or planes <= 1) else 0.5 + planes
-        alg_bytes = reads * 1.001 * wl.W * per_base + 12.0 * reads
-        assert a.rich or abs(alg_bytes - wl.algorithmic_bytes(n_reads=reads)) < 1.0
+        alg_bytes = shard_reads * 1.001 * wl.W * per_base + 12.0 * shard_reads
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # what the kernel really streams: 16 B of bit planes per 32-base group, 32 B per group for every QV plane a
+        # threshold makes it read, 12 B of tables per read (the QV planes of an unmasked or baked set are never touched)
+        real_bytes = n_bases / 32 * (16 + 32 * (0 if baked else planes)) + 12.0 * shard_reads
         kernel_name = "pileup_simple_kernel" if a.mode == "simple" else "pileup_kernel"
+        traffic = None if (a.rich or a.scaling == "strong" and world > 1) else load_traffic(kernel_name, wl.name, shard_reads, a.qualqv, baked)
+        physical = (traffic or real_bytes) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         out = {
             "metric": "aligned CCS reads/sec (pileup+Fisher, node)",
-            "value": reads * world / (dt / a.steps),
+            "value": total / (dt / a.steps),
             "unit": "reads/s",
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "u32 counts, f64 Fisher",
             "data": "synthetic",
-            "config": {"workload": "%s: %d reads/GPU x %d columns (HXB2 pol, 1%% minors), QUALQV=%s" % (
-                wl.name, reads, W, "unset" if a.qualqv < 0 else a.qualqv) + (", rich QVs, SUBQV=42" if a.rich else ""), "mode": a.mode,
-                "window_bounds": "host round trip per step" if step is step_host_bounds else "device-resident",
-                "column_slabs": (part.n_slabs if part else (((W + 31) // 32) + 127) // 128),
-                "read_layout": "column-slab partition (built at set-up)" if part else "one read set",
-                "qv_thresholds": "unset" if a.qualqv < 0 and not a.rich else "applied at pack time (baked)" if baked else "applied in every pass",
-                "bases_per_gpu": int(n_bases), "codon_positions": plan.P, "number_of_tests": int(plan.n_tests.item())},
+            "config": {"workload": "%s: %d reads/GPU x %d columns (%d minor clones at %g %% each in %d codons, %g substitutions/base), QUALQV=%s" % (
+                wl.name, shard_reads, W, wl.params.n_minors, 100.0 * wl.params.thr_minor / 4294967296.0,
+                len([s for s in wl.minor_sites if s[0] == 1]), wl.params.thr_sub / 4294967296.0,
+                "unset" if a.qualqv < 0 else a.qualqv) + (", rich QVs, SUBQV=42" if a.rich else ""), "mode": a.mode,
+                "window": {"known": "known at set-up; bounds recomputed per step in the prologue launch and checked",
+                           "device": "discovered on the device per step", "host": "host round trip per step"}[flow],
+                "exchange": ("one RCCL group per step (bounds MAX + counts SUM), library communicator" if flow == "known"
+                             else "two RCCL all-reduces per step, library communicator") if multi else "none (one GPU)",
+                "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 127) // 128),
+                "read_layout": "column-slab partition (built at set-up)" if n_slabs else "one read set",
+                "qv_thresholds": "unset" if a.qualqv < 0 and not a.rich else "applied at pack time (baked; the bake pass is set-up, not timed)" if baked else "applied in every pass",
+                "bases_per_gpu": int(n_bases), "codon_positions": P, "number_of_tests": n_tests,
+                "bases_off_majority": dev_share},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if a.rich else load_traffic(kernel_name, wl.name, reads, a.qualqv, baked),
-                         "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes, "timed_steps": timed_steps,
+                         # the physical side of the same launch: bytes really moved (PMC traffic when a pass of this
+                         # exact configuration is committed, else the bytes the kernel streams) over the same time
+                         "streamed_bytes": real_bytes, "physical_gbs": physical, "frac_physical": physical / HBM_PEAK_GBS,
+                         "limiter": "valu/latency" if physical < 0.5 * HBM_PEAK_GBS else "hbm",
+                         # K1 + fold [+ exchange] + K2, SURVEY 8d's t_kernel(K1 + K2)
+                         "path_ms": path_ms, "frac_path": (alg_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_ms else None},
         }
+        if secondary is not None:
+            out["strong_scaling"] = secondary
+        if verified is not None:
+            out["verified_against_simple_kernel"] = verified
         if cpu is not None:
             out["cpu_baseline"] = cpu
         if pcie is not None:
             out["pcie_inclusive"] = pcie
-        print(json.dumps(out), flush=True)
-    if world > 1 or a.force_dist:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if multi:
+        ex.close()
         dist.destroy_process_group()
 
 

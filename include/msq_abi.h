@@ -172,6 +172,12 @@ int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* be
  * yields the global window.  No reads: {-INT32_MAX, 0}.  Enqueued on the stream, does not synchronise. */
 int msq_window_bounds_device(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_bounds);
 
+/* The first half of MSAByRow's constructor in one launch, for steps that run back to back on the stream:
+ * msq_window_bounds_device (UpdateBoundaries over the reads, src/MSA.cpp:96-97,138-142) plus the count matrices
+ * cleared (rows start blank and MSAColumn counts at 0, include/pacbio/data/MSA.h:99-101,194): d_counts[0 .. n_words)
+ * = 0, typically the caller's [W][6] and [W][64] matrices in one buffer.  Async. */
+int msq_pileup_begin(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_bounds, uint32_t* d_counts, size_t n_words);
+
 /* MSAByRow::MSAByRow + MSAByColumn::MSAByColumn + MSAByRow::CodonsAt for every column
  * (src/MSA.cpp:55-92, 94-136, 144-219) as two dense count matrices, ADDED into the caller's buffers:
  *   d_nuc  [W][6]  u32, bins A C G T - N            == MSAColumn::counts_ (MSA.h:194)
@@ -267,6 +273,44 @@ int msq_insertion_records(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t
  * max_records == 0 disables.  bench.py uses this for the roofline figure. */
 int msq_timing_enable(msq_ctx* ctx, int32_t max_records);
 int msq_timing_read(msq_ctx* ctx, float* ms_out, int32_t capacity, int32_t* n_out);
+/* The same with only every stride-th pileup timed (an event pair costs the stream two ~5 us bubbles, which is
+ * visible in a 0.1 ms step), and, for the timed pileups, a third event behind the msq_call_cells that follows:
+ * msq_timing_read_path returns begin-of-pileup-kernel .. end-of-testing-pass (K1 + fold [+ the count all-reduce]
+ * + K2, what SURVEY 8d calls t_kernel(K1 + K2)).  Call it before msq_timing_read, which resets the records. */
+int msq_timing_enable_strided(msq_ctx* ctx, int32_t max_records, int32_t stride);
+int msq_timing_read_path(msq_ctx* ctx, float* ms_out, int32_t capacity, int32_t* n_out);
+
+/* ---------------------------------------------------------------------------------- read shards over the GPUs
+ * No counterpart in the reference (a single process): the exchange step the north star prescribes when the reads
+ * of one sample are sharded over the GPUs of a node, one process (and one context) per GPU -- RCCL collectives
+ * over xGMI on the context's stream.  Counts are additive integers and the window is a min / max, so every rank
+ * ends up with bit-identical matrices and the testing pass (msq_call_cells) runs replicated, with no broadcast.
+ *   rank 0:      msq_comm_unique_id(id)            -> hand the 128 bytes to every rank (MPI, a file, any store)
+ *   every rank:  msq_comm_create(ctx, rank, world, id)
+ *   per step:    msq_window_bounds_device -> msq_comm_allreduce_bounds -> msq_pileup_device_window (own shard)
+ *                -> msq_comm_allreduce_counts -> msq_call_cells
+ *   or, when the window is known beforehand (a target region):
+ *                msq_pileup_begin -> msq_pileup(begin0, W) -> msq_comm_allreduce_step (ONE RCCL group: bounds MAX +
+ *                counts SUM) -> msq_call_cells, and the caller compares the reduced bounds with its window.
+ * A context without a communicator treats every msq_comm_allreduce_* as a no-op (one GPU: the shard is the sample).
+ * RCCL (librccl.so.1) is loaded when the first msq_comm_* call needs it; the single-GPU path does not depend on it. */
+#define MSQ_COMM_ID_BYTES 128
+int msq_comm_unique_id(uint8_t* id_out /* [MSQ_COMM_ID_BYTES] */);   /* host */
+int msq_comm_create(msq_ctx* ctx, int rank, int world, const uint8_t* id);  /* collective over the ranks; synchronises */
+int msq_comm_destroy(msq_ctx* ctx);
+int msq_comm_rank(const msq_ctx* ctx);   /* 0 without a communicator */
+int msq_comm_world(const msq_ctx* ctx);  /* 1 without a communicator */
+/* Contiguous read range of a rank, [rank * N / world, (rank + 1) * N / world).  Host. */
+int msq_comm_shard(uint64_t n_reads, int rank, int world, uint64_t* first, uint64_t* count);
+/* d_bounds = {-begin0, end0} as msq_window_bounds_device left it: element-wise MAX over the ranks, in place. */
+int msq_comm_allreduce_bounds(msq_ctx* ctx, int32_t* d_bounds);
+/* u32 SUM over the ranks, in place: the [W][6] + [W][64] count matrices (global read count < 2^32). */
+int msq_comm_allreduce_counts(msq_ctx* ctx, uint32_t* d_counts, size_t n);
+/* Both of the above as one RCCL group (one launch). */
+int msq_comm_allreduce_step(msq_ctx* ctx, int32_t* d_bounds, uint32_t* d_counts, size_t n);
+/* Every rank's bytes_per_rank bytes, concatenated in rank order into d_recv [world * bytes_per_rank] (the phasing
+ * keys of the shards, when PhaseVariants runs on a sharded sample).  Without a communicator: a copy. */
+int msq_comm_allgather(msq_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 
 /* ------------------------------------------------------------------------------------------ cell testing
  * A plan fixes which (gene, codon position) pairs AminoAcidCaller::CallVariants visits

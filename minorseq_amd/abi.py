@@ -19,6 +19,7 @@ MSQ_READS_NORMALIZED = 2
 MSQ_READS_PAD_MARKED = 4
 MSQ_READS_QV_BAKED = 8
 MSQ_PACK_PLAIN = 1
+MSQ_COMM_ID_BYTES = 128
 
 
 class MsqError(RuntimeError):
@@ -114,6 +115,19 @@ _SIGNATURES = {
     "msq_pileup_noalloc": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P]),
     "msq_pileup_check": (C.c_int, [_P]),
     "msq_phase_codons": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "msq_pileup_begin": (C.c_int, [_P, C.POINTER(PackedReads), _P, _P, C.c_size_t]),
+    "msq_timing_enable_strided": (C.c_int, [_P, C.c_int32, C.c_int32]),
+    "msq_timing_read_path": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
+    "msq_comm_unique_id": (C.c_int, [_P]),
+    "msq_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "msq_comm_destroy": (C.c_int, [_P]),
+    "msq_comm_rank": (C.c_int, [_P]),
+    "msq_comm_world": (C.c_int, [_P]),
+    "msq_comm_shard": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "msq_comm_allreduce_bounds": (C.c_int, [_P, _P]),
+    "msq_comm_allreduce_counts": (C.c_int, [_P, _P, C.c_size_t]),
+    "msq_comm_allreduce_step": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "msq_comm_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "msq_timing_enable": (C.c_int, [_P, C.c_int32]),
     "msq_timing_read": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "msq_plan_create": (C.c_int, [_P, C.c_int32, _P, _P, C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_P)]),

@@ -390,6 +390,7 @@ extern "C" int msq_call_cells(msq_ctx* ctx, const msq_plan* plan, const uint32_t
     hipLaunchKernelGGL(call_cells_kernel, dim3(blocks), dim3(256), 0, ctx->stream, plan->d_pos, plan->P, plan->begin1,
                        plan->W, plan->has_reference ? 1 : 0, d_codon, lf, *em, maximal_perc, d_n_tests, d_positions, d_p,
                        d_expected, ctx->d_err);
+    msq_timing_mark_path_end(ctx);
     MSQ_HIP(hipGetLastError());
     return MSQ_OK;
 }

@@ -76,6 +76,7 @@ extern "C" int msq_ctx_destroy(msq_ctx* ctx)
     if (!ctx) return MSQ_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)msq_comm_destroy(ctx);
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_lfact) (void)hipFree(ctx->d_lfact);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -145,47 +146,81 @@ static void timing_release(msq_ctx* ctx)
 {
     for (auto e : ctx->ev_begin) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_end) (void)hipEventDestroy(e);
+    for (auto e : ctx->ev_path_end) (void)hipEventDestroy(e);
     ctx->ev_begin.clear();
     ctx->ev_end.clear();
+    ctx->ev_path_end.clear();
     ctx->ev_used = 0;
+    ctx->ev_calls = 0;
+    ctx->ev_open = ctx->ev_path_open = false;
 }
 
-extern "C" int msq_timing_enable(msq_ctx* ctx, int32_t max_records)
+extern "C" int msq_timing_enable_strided(msq_ctx* ctx, int32_t max_records, int32_t stride)
 {
-    if (!ctx || max_records < 0) return msq_fail(MSQ_ERR_ARG, "msq_timing_enable: bad argument");
+    if (!ctx || max_records < 0 || stride < 1) return msq_fail(MSQ_ERR_ARG, "msq_timing_enable: bad argument");
     MSQ_HIP(hipSetDevice(ctx->device));
     MSQ_HIP(hipStreamSynchronize(ctx->stream));
     timing_release(ctx);
+    ctx->ev_stride = stride;
     for (int i = 0; i < max_records; ++i) {
-        hipEvent_t a, b;
+        hipEvent_t a, b, c;
         MSQ_HIP(hipEventCreate(&a));
         MSQ_HIP(hipEventCreate(&b));
+        MSQ_HIP(hipEventCreate(&c));
         ctx->ev_begin.push_back(a);
         ctx->ev_end.push_back(b);
+        ctx->ev_path_end.push_back(c);
     }
+    return MSQ_OK;
+}
+extern "C" int msq_timing_enable(msq_ctx* ctx, int32_t max_records) { return msq_timing_enable_strided(ctx, max_records, 1); }
+
+// kernel_ms_out: begin .. end of the dominant kernel; path_ms_out: begin .. end of msq_call_cells (either may be NULL)
+static int timing_read(msq_ctx* ctx, float* kernel_ms_out, float* path_ms_out, int32_t capacity, int32_t* n_out)
+{
+    float* ms_out = kernel_ms_out ? kernel_ms_out : path_ms_out;
+    if (!ctx || !n_out || (capacity > 0 && !ms_out)) return msq_fail(MSQ_ERR_ARG, "msq_timing_read: bad argument");
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    int n = ctx->ev_used < capacity ? ctx->ev_used : capacity;
+    for (int i = 0; i < n; ++i)
+        MSQ_HIP(hipEventElapsedTime(&ms_out[i], ctx->ev_begin[i], kernel_ms_out ? ctx->ev_end[i] : ctx->ev_path_end[i]));
+    *n_out = n;
+    if (!path_ms_out) ctx->ev_used = 0;
     return MSQ_OK;
 }
 
 extern "C" int msq_timing_read(msq_ctx* ctx, float* ms_out, int32_t capacity, int32_t* n_out)
 {
-    if (!ctx || !n_out || (capacity > 0 && !ms_out)) return msq_fail(MSQ_ERR_ARG, "msq_timing_read: bad argument");
-    MSQ_HIP(hipStreamSynchronize(ctx->stream));
-    int n = ctx->ev_used < capacity ? ctx->ev_used : capacity;
-    for (int i = 0; i < n; ++i) MSQ_HIP(hipEventElapsedTime(&ms_out[i], ctx->ev_begin[i], ctx->ev_end[i]));
-    *n_out = n;
-    ctx->ev_used = 0;
-    return MSQ_OK;
+    return timing_read(ctx, ms_out, nullptr, capacity, n_out);
+}
+extern "C" int msq_timing_read_path(msq_ctx* ctx, float* ms_out, int32_t capacity, int32_t* n_out)
+{
+    if (ctx && ctx->ev_path_open) return msq_fail(MSQ_ERR_ARG, "msq_timing_read_path: the last timed pileup has no msq_call_cells behind it");
+    return timing_read(ctx, nullptr, ms_out, capacity, n_out);
 }
 
 void msq_timing_mark_begin(msq_ctx* ctx)
 {
-    if (ctx->ev_used < (int)ctx->ev_begin.size()) (void)hipEventRecord(ctx->ev_begin[ctx->ev_used], ctx->stream);
+    ctx->ev_open = false;
+    if (ctx->ev_used < (int)ctx->ev_begin.size() && (ctx->ev_calls++ % ctx->ev_stride) == 0) {
+        (void)hipEventRecord(ctx->ev_begin[ctx->ev_used], ctx->stream);
+        ctx->ev_open = true;
+    }
 }
 void msq_timing_mark_end(msq_ctx* ctx)
 {
-    if (ctx->ev_used < (int)ctx->ev_begin.size()) {
+    if (ctx->ev_open) {
         (void)hipEventRecord(ctx->ev_end[ctx->ev_used], ctx->stream);
         ++ctx->ev_used;
+        ctx->ev_open = false;
+        ctx->ev_path_open = true;
+    }
+}
+void msq_timing_mark_path_end(msq_ctx* ctx)  // behind msq_call_cells' last kernel
+{
+    if (ctx->ev_path_open) {
+        (void)hipEventRecord(ctx->ev_path_end[ctx->ev_used - 1], ctx->stream);
+        ctx->ev_path_open = false;
     }
 }
 

@@ -18,8 +18,11 @@ enum : int { SYM_BLANK = 0, SYM_A = 1, SYM_C = 2, SYM_G = 3, SYM_T = 4, SYM_GAP 
 // Device-side deferred error word (bit set): reported by msq_pileup_check / msq_call_check.
 enum : uint32_t { DEVERR_BASE = 1u, DEVERR_WINDOW = 2u, DEVERR_RANGE = 4u, DEVERR_EXOTIC = 8u };
 
+struct msq_comm;  // msq_comm.hip: the RCCL communicator of a context that is one rank of a read-sharded run
+
 struct msq_ctx {
     int device = 0;
+    msq_comm* comm = nullptr;
     hipStream_t stream = nullptr;
     uint32_t* d_err = nullptr;      // [1] deferred error bits
     // [48] small accumulators of kernels that finish their own reduction: all zero between kernels -- the last
@@ -41,8 +44,11 @@ struct msq_ctx {
     uint32_t* d_noalloc = nullptr;
     size_t noalloc_bytes = 0;
     // measurement aid: event pairs around the dominant pileup kernel (msq_timing_enable)
-    std::vector<hipEvent_t> ev_begin, ev_end;
-    int ev_used = 0;
+    // and, for the same records, the end of the step's last kernel (msq_call_cells): K1 .. K2 as SURVEY 8d prices it.
+    // stride: only every stride-th pileup is timed (an event costs the stream a ~5 us bubble)
+    std::vector<hipEvent_t> ev_begin, ev_end, ev_path_end;
+    int ev_used = 0, ev_stride = 1, ev_calls = 0;
+    bool ev_open = false, ev_path_open = false;
 };
 
 // Packed reads resident in HBM and owned by the library: the eight arrays of msq_packed_reads (ref_start, ref_end,
@@ -55,6 +61,7 @@ struct msq_packed_dev {
 // Record the begin / end event of the next timing slot (no-ops when timing is off or the slots are used up).
 void msq_timing_mark_begin(msq_ctx* ctx);
 void msq_timing_mark_end(msq_ctx* ctx);
+void msq_timing_mark_path_end(msq_ctx* ctx);
 
 void msq_set_error(const char* fmt, ...);
 int msq_fail(int code, const char* fmt, ...);

@@ -19,11 +19,20 @@ int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_
 // maxima start from 0.  acc lives in the context's small accumulators, which are all zero between kernels: the
 // workgroup that draws the last ticket (acc[2]) reads the maxima back through atomics, writes {-begin0, end0}
 // (endPos_ never drops below its initial 0) to `out` and clears acc -- no memset before, no kernel after.
+// zero / zero_words: msq_pileup_begin's count matrices, cleared by the same launch (MSARow(size) rows start blank,
+// MSAColumn counts start at 0); NULL / 0 for the plain bounds call.
 __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __restrict__ ref_start, const int32_t* __restrict__ ref_end,
-                                                            uint64_t n, uint32_t* __restrict__ acc, int32_t* __restrict__ out)
+                                                            uint64_t n, uint32_t* __restrict__ acc, int32_t* __restrict__ out,
+                                                            uint32_t* __restrict__ zero, uint64_t zero_words)
 {
     int32_t lo = INT_MAX, hi = INT_MIN;
     const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x, nthr = (uint64_t)gridDim.x * blockDim.x;
+    if (zero_words) {  // stores first: they retire while the loads below are in flight
+        const uint64_t z4 = ((uintptr_t)zero & 15u) ? 0 : zero_words / 4;
+        uint4* zq = reinterpret_cast<uint4*>(zero);
+        for (uint64_t i = tid; i < z4; i += nthr) zq[i] = make_uint4(0, 0, 0, 0);
+        for (uint64_t i = z4 * 4 + tid; i < zero_words; i += nthr) zero[i] = 0;
+    }
     const uint64_t n4 = (((uintptr_t)ref_start | (uintptr_t)ref_end) & 15u) ? 0 : n / 4;  // 16-byte loads when aligned
     const int4* s4 = reinterpret_cast<const int4*>(ref_start);
     const int4* e4 = reinterpret_cast<const int4*>(ref_end);
@@ -79,12 +88,14 @@ __global__ __launch_bounds__(256) void window_bounds_kernel(const int32_t* __res
     }
 }
 
-static int launch_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_out)
+static int launch_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_out, uint32_t* d_zero = nullptr,
+                                uint64_t zero_words = 0)
 {
     uint64_t blocks = (d_reads->n_reads / 4 + 255) / 256;
+    if (zero_words) blocks = 128;
     blocks = blocks < 1 ? 1 : blocks > 128 ? 128 : blocks;  // few blocks: their same-address atomics serialise
     hipLaunchKernelGGL(window_bounds_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_reads->ref_start,
-                       d_reads->ref_end, d_reads->n_reads, ctx->d_small, d_out);
+                       d_reads->ref_end, d_reads->n_reads, ctx->d_small, d_out, d_zero, zero_words);
     MSQ_HIP(hipGetLastError());
     return MSQ_OK;
 }
@@ -100,6 +111,20 @@ extern "C" int msq_window_bounds_device(msq_ctx* ctx, const msq_packed_reads* d_
         return MSQ_OK;
     }
     return launch_window_bounds(ctx, d_reads, d_bounds);
+}
+
+extern "C" int msq_pileup_begin(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_bounds, uint32_t* d_counts, size_t n_words)
+{
+    if (!ctx || !d_reads || !d_bounds || (!d_counts && n_words)) return msq_fail(MSQ_ERR_ARG, "msq_pileup_begin: NULL argument");
+    if (d_reads->n_reads && (!d_reads->ref_start || !d_reads->ref_end)) return msq_fail(MSQ_ERR_ARG, "msq_pileup_begin: NULL ref arrays");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    if (d_reads->n_reads == 0) {
+        const int32_t none[2] = {-INT_MAX, 0};
+        MSQ_HIP(hipMemcpyAsync(d_bounds, none, sizeof(none), hipMemcpyHostToDevice, ctx->stream));
+        if (n_words) MSQ_HIP(hipMemsetAsync(d_counts, 0, n_words * sizeof(uint32_t), ctx->stream));
+        return MSQ_OK;
+    }
+    return launch_window_bounds(ctx, d_reads, d_bounds, d_counts, n_words);
 }
 
 extern "C" int msq_window_bounds(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* begin0, int32_t* end0)

@@ -1,0 +1,109 @@
+"""The exchange step behind the C ABI (msq_comm_*, RCCL on the context's stream) with the one rank a one-GPU box
+offers: the communicator comes up from its 128-byte id, every collective leaves a one-rank buffer as it was, the
+whole sharded step (prologue -> pileup -> one RCCL group -> testing pass) equals the plain calls, and the shard
+rule partitions the reads.  The N = 2 arithmetic is covered on CPU (tests/test_sharding_gloo.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from minorseq_amd import abi, device, sharding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cx():
+    c = device.Ctx(0)
+    ex = sharding.LibExchange(c, 0, 1, lambda raw: raw)
+    yield c, ex
+    ex.close()
+    c.close()
+
+
+def test_pileup_begin_bounds_and_cleared_matrices(ctx):
+    L = abi.lib()
+    for reads in (cases.random_reads(5, 300, 700, p_ins=0.05), cases.random_reads(6, 3, 90), cases.make_reads([])):
+        dr = device.upload(device.pack_host(reads), ctx.device)
+        b, e = device.window_bounds(ctx, dr)
+        for n_words in (0, 1, 5, 70 * 701, 4096):
+            buf = torch.full((max(n_words, 1) + 8,), 7, dtype=torch.int32, device="cuda")
+            bounds = torch.full((2,), 99, dtype=torch.int32, device="cuda")
+            abi.check(L.msq_pileup_begin(ctx.h, dr.view, bounds.data_ptr(), buf[4:].data_ptr(), n_words))  # 16-byte aligned start
+            assert bounds.tolist() == [-b, e]
+            got = buf.cpu().numpy()
+            assert (got[:4] == 7).all() and (got[4:4 + n_words] == 0).all() and (got[4 + n_words:] == 7).all()
+            if n_words > 3:  # a start that is not 16-byte aligned
+                buf.fill_(7)
+                abi.check(L.msq_pileup_begin(ctx.h, dr.view, bounds.data_ptr(), buf[1:].data_ptr(), n_words - 3))
+                got = buf.cpu().numpy()
+                assert got[0] == 7 and (got[1:n_words - 2] == 0).all() and (got[n_words - 2:] == 7).all()
+
+
+def test_one_rank_collectives_are_identities(cx):
+    ctx, ex = cx
+    L = abi.lib()
+    assert (L.msq_comm_rank(ctx.h), L.msq_comm_world(ctx.h)) == (0, 1)
+    bounds = torch.tensor([-2252, 5095], dtype=torch.int32, device="cuda")
+    counts = torch.arange(70 * 300, dtype=torch.int32, device="cuda")
+    want = counts.clone()
+    ex.allreduce_bounds_device(bounds)
+    ex.allreduce_counts(counts)
+    ex.allreduce_step(bounds, counts)
+    assert bounds.tolist() == [-2252, 5095] and torch.equal(counts, want)
+    assert ex.allreduce_bounds(2252, 5095) == (2252, 5095)
+    out = torch.zeros_like(counts)
+    abi.check(L.msq_comm_allgather(ctx.h, counts.data_ptr(), out.data_ptr(), counts.numel() * 4))
+    assert torch.equal(out, want)
+    # a second communicator on the same context is refused, bad ranks too
+    uid = (C.c_uint8 * abi.MSQ_COMM_ID_BYTES)()
+    assert L.msq_comm_create(ctx.h, 0, 1, uid) == abi.MSQ_ERR_ARG
+    other = device.Ctx(0)
+    assert L.msq_comm_create(other.h, 2, 2, uid) == abi.MSQ_ERR_ARG
+    # no communicator: every exchange is a no-op
+    abi.check(L.msq_comm_allreduce_step(other.h, bounds.data_ptr(), counts.data_ptr(), counts.numel()))
+    assert torch.equal(counts, want)
+    other.close()
+
+
+def test_sharded_step_equals_plain_calls(cx):
+    """Two shards of one sample pushed through the sharded step one after the other on the one rank there is, added up
+    by hand where the all-reduce would add them: the global window and the whole sample's matrices and calls."""
+    ctx, ex = cx
+    L = abi.lib()
+    wl = synth.workload("hiv_1k", n_reads=900)  # staggered reads: the shards see different windows
+    thr = abi.QvThresholds.make()
+    whole = device.synth_device(ctx, wl, 0, 900)
+    b0, e0 = device.window_bounds(ctx, whole)
+    W = e0 - b0
+    want_n, want_c = device.pileup(ctx, whole, thr, b0, W)
+    total = torch.zeros(W * 70, dtype=torch.int32, device="cuda")
+    glob = torch.tensor([-(2 ** 31 - 1), 0], dtype=torch.int32, device="cuda")
+    for r in range(2):
+        first, n = sharding.shard_range(900, r, 2)
+        shard = device.synth_device(ctx, wl, first, n)
+        counts = torch.full((W * 70,), -1, dtype=torch.int32, device="cuda")
+        bounds = torch.zeros(2, dtype=torch.int32, device="cuda")
+        abi.check(L.msq_pileup_begin(ctx.h, shard.view, bounds.data_ptr(), counts.data_ptr(), counts.numel()))
+        abi.check(L.msq_pileup(ctx.h, shard.view, thr, b0, W, counts[:W * 6].data_ptr(), counts[W * 6:].data_ptr(), abi.MSQ_PILEUP_AUTO))
+        ex.allreduce_step(bounds, counts)
+        abi.check(L.msq_pileup_check(ctx.h))
+        total += counts
+        glob = torch.maximum(glob, bounds)
+    assert glob.tolist() == [-b0, e0]
+    assert torch.equal(total[:W * 6], want_n) and torch.equal(total[W * 6:], want_c)
+
+
+def test_shard_rule_matches_the_library():
+    L = abi.lib()
+    for n in (0, 1, 7, 1000003, 2 ** 40 + 5):
+        for world in (1, 2, 3, 8):
+            nxt = 0
+            for r in range(world):
+                f, c = C.c_uint64(), C.c_uint64()
+                abi.check(L.msq_comm_shard(n, r, world, C.byref(f), C.byref(c)))
+                assert (f.value, c.value) == sharding.shard_range(n, r, world) and f.value == nxt
+                nxt += c.value
+            assert nxt == n

@@ -24,6 +24,18 @@ def test_shard_range_partitions():
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
 
 
+def test_shard_range_is_the_library_rule():
+    """msq_comm_shard (host arithmetic, no GPU and no RCCL needed): [r N / P, (r + 1) N / P)."""
+    import ctypes as C
+    from minorseq_amd import abi
+    for n in (0, 5, 1000003, 2 ** 40 + 5):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                f, c = C.c_uint64(), C.c_uint64()
+                abi.check(abi.lib().msq_comm_shard(n, r, world, C.byref(f), C.byref(c)))
+                assert (f.value, c.value) == sharding.shard_range(n, r, world)
+
+
 def _rank_main(rank, world, port, n_reads, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
