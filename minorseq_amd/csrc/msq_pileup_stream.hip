@@ -36,21 +36,33 @@
 // MSQ_EXP: compile-time timing experiments only (make EXTRA=-DMSQ_EXP=n); any non-zero value gives WRONG counts.
 // bit 0 skip the LDS ORs of phase 1, bit 1 skip phase 2 + drain, bit 2 skip the squeeze, bit 3 skip the drain,
 // bit 4 skip zero_rows, bit 5 skip the counter transposition of the flush.  The shipped library is always built with 0.
+#ifndef MSQ_W12
+#define MSQ_W12 0
+#endif
 #ifndef MSQ_EXP
 #define MSQ_EXP 0
 #endif
 
 namespace {
 
-constexpr int kLevels = 10;       // bit-sliced counter depth: 1023 reads per wave and launch (register arrays are sized for it)
+#ifndef MSQ_LEVELS
+#define MSQ_LEVELS 10
+#endif
+#ifndef MSQ_FA
+#define MSQ_FA 1
+#endif
+#ifndef MSQ_NS0
+#define MSQ_NS0 4
+#endif
+constexpr int kLevels = MSQ_LEVELS;       // bit-sliced counter depth: 1023 reads per wave and launch (register arrays are sized for it)
 constexpr int kLowLevels = 6;     // levels rippled on every add; the upper ones only when a carry reaches them
 constexpr int kRows = 8;          // reads per wave batch
 constexpr int kMaxBatchesPerWave = ((1 << kLevels) - 1) / kRows;
 
 // Waves per workgroup (one workgroup per CU): 12 = 3 per SIMD where the kernel fits 168 VGPRs, else 8 = 2 per SIMD.
-constexpr int max_waves_of(int np, int passes) { return (passes == 1 && np <= 2) ? 12 : 8; }
+constexpr int max_waves_of(int np, int passes) { return ((passes == 1 && np <= 2) || (MSQ_W12 && np == 0)) ? 12 : 8; }
 // Register slots of the chunk pipeline (NS - 1 chunk loads in flight behind the chunk being decoded).
-constexpr int slots_of(int np, int /*passes*/) { return np == 0 ? 4 : np == 1 ? 3 : 2; }
+constexpr int slots_of(int np, int /*passes*/) { return np == 0 ? MSQ_NS0 : np == 1 ? 3 : 2; }
 
 struct StreamArgs {
     const int32_t* ref_start;
@@ -260,54 +272,130 @@ struct Slot {  // one chunk (64 groups) in flight
     uint4 qa[NP ? NP : 1], qb[NP ? NP : 1];
 };
 
+__device__ __forceinline__ uint4 buffer_load16(__amdgpu_buffer_rsrc_t r, uint32_t voffset, uint32_t soffset)
+{
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voffset, (int)soffset, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // constant address space + uniform index = s_load (the arrays are read-only for the whole launch)
 typedef const uint64_t __attribute__((address_space(4))) * const_u64_ptr;
 typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
 
-// Producer side: walks this wave's batches b = wid, wid + TW, ... and yields the group range of the next chunk
-// to load.  Every field is wave-uniform (SGPRs); the next batch's range is fetched one batch ahead.
+// Which batches a wave takes.  The waves of a workgroup do not run at the same speed (of the two waves of a SIMD the
+// older one wins the issue arbitration: with a fixed share per wave the older ones sat idle for the last ~13 % of
+// the kernel), so they DRAW their batches from one LDS counter: the t-th draw of the workgroup is batch
+// t * gridDim.x + blockIdx.x.  A draw is an LDS atomic whose result is looked at one batch later; the ids of the
+// wave's last few batches sit in one VGPR (lane s & 3 = the wave's s-th batch, ~0 = none left), where both the
+// producer (up to two batches ahead) and the consumer find them.  A wave stops drawing at `cap` batches, what its
+// bit-sliced counters hold.
+struct BatchDraw {
+    uint32_t* ctr;
+    uint32_t stride, first, n_batches, cap;
+    uint32_t ring;     // VGPR
+    uint32_t pending;  // VGPR: lane 0 = the draw in flight
+    uint32_t n_res, n_issued;
+
+    __device__ __forceinline__ void draw(int lane)
+    {
+        pending = 0xffffffffu;
+        if (n_issued < cap) {  // wave-uniform
+            if (lane == 0) pending = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        n_issued = uni(n_issued + 1u);
+    }
+    __device__ __forceinline__ void resolve(int lane)
+    {
+        const uint32_t t = uni(pending);
+        uint32_t bid = t == 0xffffffffu ? 0xffffffffu : t * stride + first;
+        if (bid >= n_batches) bid = 0xffffffffu;
+        ring = (uint32_t)lane == (n_res & 3u) ? uni(bid) : ring;
+        n_res = uni(n_res + 1u);
+    }
+    __device__ __forceinline__ uint32_t id(uint32_t s) const { return uni((uint32_t)__builtin_amdgcn_readlane((int)ring, (int)(s & 3u))); }
+    __device__ __forceinline__ void init(uint32_t* counter, uint32_t nb, uint32_t cap_, int lane)
+    {
+        ctr = counter;
+        stride = gridDim.x;
+        first = blockIdx.x;
+        n_batches = nb;
+        cap = cap_;
+        ring = 0xffffffffu;
+        n_res = n_issued = 0;
+        for (int k = 0; k < 3; ++k) {
+            draw(lane);
+            resolve(lane);
+        }
+        draw(lane);
+    }
+};
+
+// Producer side: walks this wave's batches and yields the group range of the next chunk to load.  Every field is
+// wave-uniform (SGPRs); the next batch's range is fetched one batch ahead.
 struct ChunkProducer {
     const_u64_ptr go;
     uint64_t read_lo, read_hi;
-    uint32_t n_batches, TW, b;
+    uint32_t n_batches, P;  // P: sequence number (BatchDraw) of the batch being issued
     uint64_t B0, nB0;
-    uint32_t ng, nng, c, live;
+    uint32_t ng, nng, c, live, nlive;
+    uint32_t nslots;  // chunk slots the current batch takes: its chunks rounded up to a multiple of the slot count
+    uint64_t bop_base;
+    uint64_t cur_base;  // the bit planes' buffer resource over the current batch: base address and bytes
+    uint32_t cur_bytes;
 
-    __device__ __forceinline__ void fetch(uint32_t bb, uint64_t& o0, uint32_t& n)
+    // buffer resource over the current batch's groups of one plane (2^shift bytes per group)
+    template <typename T>
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const T* plane, int shift) const
+    {
+        const char* base = reinterpret_cast<const char*>(plane) + (B0 << shift);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, (int)((live ? ng : 0u) << shift), 0x00020000);
+    }
+    __device__ __forceinline__ void batch_changed(uint32_t ns)
+    {
+        const uint32_t nch = max(1u, (ng + 63u) >> 6);
+        nslots = uni((nch + ns - 1u) / ns * ns);
+        cur_base = uni64(bop_base + (B0 << 4));
+        cur_bytes = uni(live ? ng << 4 : 0u);  // zero records for a wave that has run out of batches: every load reads zeros
+    }
+    __device__ __forceinline__ void fetch(uint32_t bb, uint64_t& o0, uint32_t& n, uint32_t& alive)
     {
         o0 = 0;
         n = 0;
-        if (bb < n_batches) {
+        alive = bb < n_batches ? 1u : 0u;
+        if (alive) {
             const uint64_t r0 = read_lo + (uint64_t)bb * kRows;
             const uint64_t r1 = min(r0 + (uint64_t)kRows, read_hi);
             o0 = uni64(go[r0]);
             n = uni((uint32_t)(uni64(go[r1]) - o0));
         }
     }
-    __device__ __forceinline__ void init(const uint64_t* group_off, uint64_t lo, uint64_t hi, uint32_t nb, uint32_t wid, uint32_t tw)
+    __device__ __forceinline__ void init(const BatchDraw& bd, const uint64_t* group_off, const void* bop, uint64_t lo, uint64_t hi,
+                                         uint32_t nb, uint32_t ns)
     {
         go = (const_u64_ptr)(uintptr_t)group_off;
+        bop_base = (uint64_t)(uintptr_t)bop;
         read_lo = lo; read_hi = hi; n_batches = nb;
-        TW = uni(tw);
-        b = uni(wid);
+        P = 0;
         c = 0;
-        live = b < n_batches ? 1u : 0u;
-        fetch(b, B0, ng);
-        fetch(b + TW, nB0, nng);
+        fetch(bd.id(0), B0, ng, live);
+        fetch(bd.id(1), nB0, nng, nlive);
+        batch_changed(ns);
     }
     // after a chunk slot of a live batch has been issued; a batch takes a multiple of `ns` slots (the tail ones
     // carry no chunk), so that slot k of the register pipeline always holds chunks k, k + ns, ... of a batch
-    __device__ __forceinline__ void advance(uint32_t ns)
+    __device__ __forceinline__ void advance(BatchDraw& bd, uint32_t ns, int lane)
     {
         c = uni(c + 1);
-        const uint32_t nch = max(1u, (ng + 63u) >> 6);
-        if (c >= (nch + ns - 1u) / ns * ns) {
-            b = uni(b + TW);
+        if (c >= nslots) {
+            P = uni(P + 1u);
             B0 = nB0;
             ng = nng;
+            live = nlive;
             c = 0;
-            live = b < n_batches ? 1u : 0u;
-            fetch(b + TW, nB0, nng);
+            bd.resolve(lane);  // the draw of a batch ago: sequence number P + 2
+            fetch(bd.id(P + 1u), nB0, nng, nlive);
+            bd.draw(lane);
+            batch_changed(ns);
         }
     }
 };
@@ -321,7 +409,7 @@ struct BatchConsumer {
     const uint32_t* go32;  // group_off viewed as dwords (a batch spans < 2^32 groups: low dwords suffice)
     const int32_t* rs;
     uint64_t read_lo, read_hi;
-    uint32_t n_batches, TW, b;
+    uint32_t n_batches, Cn, b;  // Cn: sequence number (BatchDraw) of the batch being decoded, b: its batch index
     int32_t win;
     uint32_t live;
     uint32_t bqv;        // VGPR
@@ -338,8 +426,9 @@ struct BatchConsumer {
         n_go = go32[2 * min(r0 + (uint64_t)min(lane, kRows), read_hi)];
         n_rs = rs[min(r0 + (uint64_t)min(lane, kRows - 1), read_hi - 1)];
     }
-    __device__ __forceinline__ void begin(int lane)  // make the prefetched batch current
+    __device__ __forceinline__ void begin(const BatchDraw& bd, int lane)  // make the prefetched batch current
     {
+        b = bd.id(Cn);
         live = b < n_batches ? 1u : 0u;
         if (live) {
             const uint32_t rel = n_go - (uint32_t)__builtin_amdgcn_readlane((int)n_go, 0);
@@ -355,23 +444,22 @@ struct BatchConsumer {
             C = 0;
         }
     }
-    __device__ __forceinline__ void prefetch_next(int lane) { fetch(b + TW, lane); }
-    __device__ __forceinline__ void init(const uint64_t* group_off, const int32_t* ref_start, uint64_t lo, uint64_t hi, uint32_t nb,
-                                         int32_t win_begin0, uint32_t wid, uint32_t tw, int lane)
+    __device__ __forceinline__ void prefetch_next(const BatchDraw& bd, int lane) { fetch(bd.id(Cn + 1u), lane); }
+    __device__ __forceinline__ void init(const BatchDraw& bd, const uint64_t* group_off, const int32_t* ref_start, uint64_t lo, uint64_t hi,
+                                         uint32_t nb, int32_t win_begin0, int lane)
     {
         go32 = reinterpret_cast<const uint32_t*>(group_off);
         rs = ref_start;
         read_lo = lo; read_hi = hi; n_batches = nb;
         win = win_begin0;
-        TW = uni(tw);
-        b = uni(wid);
-        fetch(b, lane);
-        begin(lane);
+        Cn = 0;
+        fetch(bd.id(0), lane);
+        begin(bd, lane);
     }
-    __device__ __forceinline__ void next(int lane)
+    __device__ __forceinline__ void next(const BatchDraw& bd, int lane)
     {
-        b = uni(b + TW);
-        begin(lane);
+        Cn = uni(Cn + 1u);
+        begin(bd, lane);
     }
 };
 
@@ -389,9 +477,14 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
 #ifdef MSQ_TRACE  // timing experiment: phase timestamps (100 MHz) of a few waves, printed at the end
     uint64_t tr_[8];
     int tr_n = 0;
+    uint64_t ta_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_ = 0;  // per-batch segments, summed: chunks, phase 2, drain, zero rows, vmcnt(0), next
 #define MSQ_TR() (tr_[tr_n++] = wall_clock64())
+#define MSQ_TA0() (tl_ = wall_clock64())
+#define MSQ_TA(k) do { const uint64_t t_ = wall_clock64(); ta_[k] += t_ - tl_; tl_ = t_; } while (0)
 #else
 #define MSQ_TR() ((void)0)
+#define MSQ_TA0() ((void)0)
+#define MSQ_TA(k) ((void)0)
 #endif
     MSQ_TR();
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, NWV = T >> 6;
@@ -414,7 +507,8 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     const int WV = kRows * ROWB + QW;                         // dwords per wave
     uint32_t* const wrow = lds + wave * WV;                   // this wave's rows
     uint16_t* const queue = reinterpret_cast<uint16_t*>(wrow + kRows * ROWB);
-    uint32_t* const gl = lds + NWV * WV;                      // the workgroup's guide words [G + 3][4]
+    uint32_t* const draw_ctr = lds + NWV * WV;                // the workgroup's batch counter (BatchDraw)
+    uint32_t* const gl = draw_ctr + 4;                        // the workgroup's guide words [G + 3][4]
 
     // ---- phase-2 identity: in pass p this lane owns word cgp[p].  The last pass, when at most 32 words wide,
     // splits the batch's rows between the two halves of the wave (rows rbase .. rbase+3).
@@ -435,32 +529,36 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         for (int i = lane * 4; i < kRows * ROWB; i += 256) *reinterpret_cast<uint4*>(&wrow[i]) = make_uint4(0, 0, 0, 0);
     };
     zero_rows();
+    if (tid == 0) *draw_ctr = 0;
     if (PHASE) {  // the guide area holds the position list instead: (window column, key index) pairs
         for (int i = tid; i < a.ph_n; i += T) {
             gl[2 * i] = (uint32_t)a.ph_pos[i];
             gl[2 * i + 1] = (uint32_t)a.ph_idx[i];
         }
-        __syncthreads();
     } else {
         for (int i = tid; i < 4 * (G + 3); i += T) gl[i] = 0;
     }
+    __syncthreads();
+    BatchDraw bd;
+    bd.init(draw_ctr, (uint32_t)a.n_batches, PHASE ? 0xffffffffu : (uint32_t)kMaxBatchesPerWave, lane);
 
     // ---- producer: one unconditional chunk load per call (clamped addresses, no predicate around the loads)
     ChunkProducer pr;
-    pr.init(a.group_off, a.read_lo, a.read_hi, (uint32_t)a.n_batches, blockIdx.x * NWV + wave, gridDim.x * NWV);
+    pr.init(bd, a.group_off, a.bop, a.read_lo, a.read_hi, (uint32_t)a.n_batches, NS);
+    // The chunk loads are buffer loads: the resource covers exactly the producer's current batch (base = its first
+    // group, num_records = its bytes; zero records for a wave that has run out of batches), the lane's byte offset is
+    // a constant VGPR and the chunk's offset rides in the scalar operand -- no address arithmetic per load, and a
+    // slot past the batch's last group (a padding slot, the tail of the last chunk) reads zeros by the range check.
+    const uint32_t lane16 = (uint32_t)lane * 16u, lane32 = (uint32_t)lane * 32u;
     auto issue = [&](Slot<NP>& s) {
-        const bool real = pr.live && 64u * pr.c < pr.ng;  // else: a padding slot, one cache line of group 0
-        const uint64_t base = real ? pr.B0 : 0;
-        const uint32_t last = real ? pr.ng - 1u : 0u;
-        const uint32_t off = real ? 64u * pr.c : 0u;
-        const uint64_t g = base + min(off + (uint32_t)lane, last);
-        s.w = a.bop[g];
+        const uint32_t soff = uni(pr.c * 1024u);
+        s.w = buffer_load16(__builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)pr.cur_base, 0, (int)pr.cur_bytes, 0x00020000), lane16, soff);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            s.qa[k] = a.qv[k][2 * g];
-            s.qb[k] = a.qv[k][2 * g + 1];
+            s.qa[k] = buffer_load16(pr.rsrc(a.qv[k], 5), lane32, 2u * soff);
+            s.qb[k] = buffer_load16(pr.rsrc(a.qv[k], 5), lane32 + 16u, 2u * soff);
         }
-        if (pr.live) pr.advance(NS);
+        if (pr.live) pr.advance(bd, NS, lane);
     };
 
     // ---- phase 1 for one chunk: read space -> column-space planes in LDS (MSAByRow::AddRead, MSA.cpp:144-186)
@@ -538,7 +636,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         const uint4 ga = *reinterpret_cast<const uint4*>(gl + wofs), gb = *reinterpret_cast<const uint4*>(gl + wofs + 4);
         // with registers to spare (no QV planes in the load slots) all four rows are fetched up front: the LDS
         // latency is paid once per call, not once per row (the queue write between rows pins the later loads)
-        constexpr bool FETCH_AHEAD = NP == 0;
+        constexpr bool FETCH_AHEAD = NP == 0 && (MSQ_FA || PASSES == 1);
         uint4 lo4[FETCH_AHEAD ? 4 : 1], hi4[FETCH_AHEAD ? 4 : 1];
         if (FETCH_AHEAD) {
 #pragma unroll
@@ -701,19 +799,25 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     Slot<NP> sl[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) issue(sl[q]);
-    cs.init(a.group_off, a.ref_start, a.read_lo, a.read_hi, (uint32_t)a.n_batches, win_begin0, blockIdx.x * NWV + wave,
-            gridDim.x * NWV, lane);
+    cs.init(bd, a.group_off, a.ref_start, a.read_lo, a.read_hi, (uint32_t)a.n_batches, win_begin0, lane);
     // the batch's chunks, NS slots per trip in a fixed order: every wait for a slot sees the same NS - 1 younger
     // loads behind it
     auto chunks = [&]() {
         for (uint32_t k = 0; k < cs.nchunks; k += NS) {
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
+#ifdef MSQ_TRACE
+                MSQ_TA0();
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (NS - 1));  // vmcnt(NS - 1): the slot's load has arrived
+                MSQ_TA(6);
+#endif
                 if (cs.c < cs.nchunks) decode(sl[q]);
+                MSQ_TA(7);
                 issue(sl[q]);
+                MSQ_TA(8);
             }
         }
-        cs.prefetch_next(lane);
+        cs.prefetch_next(bd, lane);
         wave_sync();
     };
     // The first batch goes into the rows before the guide exists; the guide is learnt from it (the only call and
@@ -734,24 +838,30 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     }
     MSQ_TR();
     while (have) {  // a wave batch is complete in the rows
+        MSQ_TA0();
         if (PHASE) {
             gather();
         } else {
             if (!(MSQ_EXP & 2)) phase2();
             wave_sync();
+            MSQ_TA(1);
             if (!(MSQ_EXP & (2 | 8))) drain();
             else qn = 0;
+            MSQ_TA(2);
         }
         wave_sync();
         if (!(MSQ_EXP & 16)) zero_rows();
+        MSQ_TA(3);
         // gfx9 counts loads and returnless atomics / stores on one vmcnt; with both kinds pending the compiler must
         // assume out-of-order completion and drains to vmcnt(0) at every later wait.  Retire them here, once per
         // batch (behind the row clearing, which does not depend on them), so the chunk loads of the next batch
         // are waited for by count.
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         wave_sync();
-        cs.next(lane);
+        MSQ_TA(4);
+        cs.next(bd, lane);
         have = cs.live;
+        MSQ_TA(5);
         if (have) chunks();
     }
 
@@ -849,6 +959,10 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
                (unsigned long long)tr_[0], (unsigned long long)(tr_[1] - tr_[0]), (unsigned long long)(tr_[2] - tr_[1]),
                (unsigned long long)(tr_[3] - tr_[2]), (unsigned long long)(tr_[4] - tr_[3]), (unsigned long long)(tr_[5] - tr_[4]),
                (unsigned long long)(tr_[6] - tr_[5]));
+    if (lane == 0 && (wave == 0 || wave == NWV - 1) && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == gridDim.x - 1))
+        printf("      wg %3d wave %d: per-batch sums: load-wait %6llu decode %6llu issue %6llu | phase2 %6llu drain %6llu zero %5llu vmcnt0 %5llu next %5llu (x10 ns)\n", (int)blockIdx.x, wave,
+               (unsigned long long)ta_[6], (unsigned long long)ta_[7], (unsigned long long)ta_[8], (unsigned long long)ta_[1], (unsigned long long)ta_[2], (unsigned long long)ta_[3],
+               (unsigned long long)ta_[4], (unsigned long long)ta_[5]);
 #endif
 }
 
@@ -1020,7 +1134,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
       for (size_t ph0 = 0; ph0 < (phase ? ph_pos.size() : 1); ph0 += kMaxPhasePositions) {
         const int ph_n = phase ? (int)std::min<size_t>(kMaxPhasePositions, ph_pos.size() - ph0) : 0;
         const size_t wave_lds = (size_t)kRows * RD * 16 + (size_t)((kRows * G * 2 + 15) / 16) * 16;  // rows + deviation queue
-        const size_t shared_lds = std::max((size_t)(G + 3) * 16, (size_t)ph_n * 8);                      // guide words / position pairs
+        const size_t shared_lds = 16 + std::max((size_t)(G + 3) * 16, (size_t)ph_n * 8);                 // batch counter, then guide words / position pairs
         // waves per workgroup: as many as fit one CU (LDS, 2-3 waves per SIMD), one workgroup per CU
         const int max_waves = max_waves_of(np_kernel, passes);
         const int nwv = (int)std::min<size_t>(max_waves, (160 * 1024 - shared_lds - 512) / wave_lds);
