@@ -98,6 +98,8 @@ typedef struct msq_packed_reads {
 #define MSQ_READS_PAD_MARKED 4u /* plain layout whose padding slots carry op 3 + nucleotide code 3 ('P' / 'S' carry
                                    code 0): the end of a read can be told from a 'P' / 'S' op (msq_insertion_*) */
 #define MSQ_READS_QV_BAKED 8u   /* made by msq_reads_bake_qv: QV-failing match bases already read 'N', no QV planes */
+#define MSQ_READS_INS_EXOTIC 16u /* some inserted ('I') base is not ACGT: it was packed as 'A'; insertion strings taken from
+                                   the packed planes differ from the reference's there (see msq_insertion.read / first_base) */
 
 /* QvThresholds (include/pacbio/data/QvThresholds.h:44-54, src/QvThresholds.cpp:45-56): -1 = boost::none. */
 typedef struct msq_qv_thresholds {
@@ -160,6 +162,18 @@ typedef void (*msq_fill_read_fn)(void* user, uint64_t read_index, msq_array_base
 int msq_pack_reads_device_fill(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
                                const int64_t* n_bases, msq_fill_read_fn fill, void* user, uint32_t pack_flags,
                                int threads, int64_t chunk_bases, msq_packed_dev** out);
+
+/* Both packers with the run's QV thresholds applied while packing: the result is, byte for byte, what
+ * msq_reads_bake_qv(msq_pack_reads_device(...), thr) gives -- failing '=' / 'X' bases already read 'N'
+ * (src/MSA.cpp:163-166), no QV planes, MSQ_READS_QV_BAKED when a threshold met a QV some base carries -- without
+ * the QV planes ever being written to HBM and without the second pass over the set.  What MSAByRow(reads) of the C++
+ * front calls: QvThresholds() is read from the environment before the reads are packed. */
+int msq_pack_reads_device_baked(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                const msq_array_base* const* bases, const int64_t* n_bases, uint32_t pack_flags, int threads,
+                                int64_t chunk_bases, const msq_qv_thresholds* thr, msq_packed_dev** out);
+int msq_pack_reads_device_fill_baked(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                     const int64_t* n_bases, msq_fill_read_fn fill, void* user, uint32_t pack_flags,
+                                     int threads, int64_t chunk_bases, const msq_qv_thresholds* thr, msq_packed_dev** out);
 
 /* ----------------------------------------------------------------------------------------------- pileup
  * MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:96-97,138-142): begin0 = min ReferenceStart,
@@ -249,21 +263,27 @@ int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv
  * consecutive 'I' bases, stored at the window column of the op that follows them; a later run flushed at the same
  * column overwrites; a run at the very end of the read is dropped) and MSAByColumn adds up per column
  * (counts[pos].IncInsertion, src/MSA.cpp:88-90, MSA.inl:101) -- what `fuse` reads (src/tools/Fuse.cpp:99-119).
- * d_reads must be in the plain layout with marked padding (MSQ_PACK_PLAIN).  Inserted bases are not QV-filtered;
- * an inserted base that is not ACGT was packed as 'A'.  A run flushed at column W (the reference then writes out
- * of bounds) is dropped. */
+ * d_reads must be in the plain layout with marked padding (MSQ_PACK_PLAIN).  Inserted bases are not QV-filtered.
+ * A run flushed at column W (the reference then writes out of bounds) is dropped.
+ * A record carries the first 64 bases of the string at 2 bits each and, for everything the 2-bit form cannot hold,
+ * where the run sits in its read: a run longer than 64 bases, or -- in a set flagged MSQ_READS_INS_EXOTIC -- one with
+ * a non-ACGT base (packed as 'A'), is rebuilt by the caller from the read's own ArrayBases
+ * [first_base, first_base + len): the reference stores strings of any length with their literal chars
+ * (src/MSA.cpp:151-156,172-174).  The C++ front does exactly that. */
 typedef struct msq_insertion {
-    int32_t col;      /* window column (0-based) */
-    uint32_t len;     /* inserted bases, <= 64 */
-    uint64_t seq_lo;  /* 2 bits per base (A=0 C=1 G=2 T=3): base k at bits 2k..2k+1 of seq_lo (k < 32) */
-    uint64_t seq_hi;  /*                                     ... or bits 2(k-32).. of seq_hi */
+    int32_t col;         /* window column (0-based) */
+    uint32_t len;        /* inserted bases (any length) */
+    uint64_t seq_lo;     /* 2 bits per base (A=0 C=1 G=2 T=3): base k at bits 2k..2k+1 of seq_lo (k < 32) */
+    uint64_t seq_hi;     /*                                     ... or bits 2(k-32).. of seq_hi (k < 64) */
+    uint32_t read;       /* index of the read in the set */
+    uint32_t first_base; /* index of the run's first base among the read's ArrayBases */
 } msq_insertion;
 /* d_counts[col] += number of rows that record an insertion at col (any string).  Async on the stream. */
 int msq_insertion_counts(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t win_begin0, int32_t W,
                          uint32_t* d_counts);
 /* One record per (row, column) insertion, in no particular order, for the columns whose bit is set in
- * d_col_filter ([ceil(W/32)] words; NULL = all columns).  *n_out = records found; more than `capacity`, or an
- * insertion longer than 64 bases: MSQ_ERR_RANGE (d_out then holds the first `capacity`).  Synchronises. */
+ * d_col_filter ([ceil(W/32)] words; NULL = all columns).  *n_out = records found; more than `capacity`:
+ * MSQ_ERR_RANGE (d_out then holds the first `capacity`).  Synchronises. */
 int msq_insertion_records(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t win_begin0, int32_t W,
                           const uint32_t* d_col_filter, msq_insertion* d_out, uint64_t capacity, uint64_t* n_out);
 

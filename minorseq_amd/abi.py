@@ -18,6 +18,7 @@ MSQ_READS_HAS_EXOTIC = 1
 MSQ_READS_NORMALIZED = 2
 MSQ_READS_PAD_MARKED = 4
 MSQ_READS_QV_BAKED = 8
+MSQ_READS_INS_EXOTIC = 16
 MSQ_PACK_PLAIN = 1
 MSQ_COMM_ID_BYTES = 128
 
@@ -101,6 +102,8 @@ _SIGNATURES = {
     "msq_packed_dev_free": (C.c_int, [_P, _P]),
     "msq_pack_reads_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(_P)]),
     "msq_pack_reads_device_fill": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(_P)]),
+    "msq_pack_reads_device_baked": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(QvThresholds), C.POINTER(_P)]),
+    "msq_pack_reads_device_fill_baked": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(QvThresholds), C.POINTER(_P)]),
     "msq_insertion_counts": (C.c_int, [_P, C.POINTER(PackedReads), C.c_int32, C.c_int32, _P]),
     "msq_insertion_records": (C.c_int, [_P, C.POINTER(PackedReads), C.c_int32, C.c_int32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "msq_window_bounds": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -114,15 +114,20 @@ inline Bytes InflateBgzf(const MappedFile& file, unsigned threads)
     while (off < file.size()) {
         if (off + 18 > file.size() || file[off] != 31 || file[off + 1] != 139 || file[off + 2] != 8 || !(file[off + 3] & 4))
             throw std::runtime_error("not a BGZF block");
+        // nothing in the header is trusted: the extra field must lie inside the file, every subfield inside the extra
+        // field, and the block must hold its header, the 8-byte trailer (CRC32, ISIZE) and end inside the file
         const size_t xlen = U16(&file[off + 10]);
+        const size_t xend = off + 12 + xlen;
+        if (xend + 8 > file.size()) throw std::runtime_error("truncated BGZF block");
         size_t x = off + 12, bsize = 0;
-        while (x + 4 <= off + 12 + xlen) {
+        while (x + 4 <= xend) {
             const size_t slen = U16(&file[x + 2]);
+            if (x + 4 + slen > xend) throw std::runtime_error("truncated BGZF block");
             if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) bsize = (size_t)U16(&file[x + 4]) + 1;
             x += 4 + slen;
         }
-        if (!bsize || off + bsize > file.size()) throw std::runtime_error("truncated BGZF block");
-        const size_t payload = off + 12 + xlen;
+        if (!bsize || bsize < 12 + xlen + 8 || off + bsize > file.size()) throw std::runtime_error("truncated BGZF block");
+        const size_t payload = xend;
         const size_t isize = U32(&file[off + bsize - 4]);
         blocks.push_back({payload, off + bsize - 8 - payload, out, isize});
         out += isize;
@@ -397,6 +402,7 @@ private:
         for (size_t r = 0; r < n_ref; ++r) {
             if (off + 4 > data.size()) throw std::runtime_error("truncated BAM header");
             const size_t l_name = U32(&data[off]);
+            if (l_name > data.size() || off + 4 + l_name + 4 > data.size()) throw std::runtime_error("truncated BAM header");
             off += 4 + l_name + 4;
         }
         // pass 1 (cheap, sequential): record offsets, filters, idx of the kept ones

@@ -237,14 +237,23 @@ public:
         } relay{&source, {}, nullptr};
         msq_packed_dev* dev = nullptr;
         const uint32_t packFlags = insertions == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
-        const int rc = msq_pack_reads_device_fill(Msq::Context(), numReads_, source.referenceStart.data(), source.referenceEnd.data(),
-                                                  source.numBases.data(), &Relay::Fill, &relay, packFlags, 0, 0, &dev);
+        // the thresholds are fixed for the life of the MSA (MSA.h:82): they are applied while packing -- failing match
+        // bases become the 'N' AddRead writes (src/MSA.cpp:165-166) and no QV plane ever reaches HBM
+        const msq_qv_thresholds thr{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
+        const int rc = msq_pack_reads_device_fill_baked(Msq::Context(), numReads_, source.referenceStart.data(), source.referenceEnd.data(),
+                                                        source.numBases.data(), &Relay::Fill, &relay, packFlags, 0, 0, &thr, &dev);
         if (relay.error) {
             if (dev) msq_packed_dev_free(Msq::Context(), dev);
             std::rethrow_exception(relay.error);
         }
         Msq::Check(rc);
-        Finish(dev, numReads_ == 0, qv, insertions);
+        Finish(dev, numReads_ == 0, qv, insertions, [&source](uint64_t read, uint32_t first, uint32_t len) {
+            std::vector<ArrayBase> bases((size_t)source.numBases[read], ArrayBase('P', '*'));
+            source.fill(read, bases.data());
+            std::string s(len, 'A');
+            for (uint32_t i = 0; i < len; ++i) s[i] = bases[first + i].Nucleotide;
+            return s;
+        });
     }
     MSAByRow(const std::vector<std::shared_ptr<Data::ArrayRead>>& reads, InsertionMode insertions = InsertionMode::None)
     {
@@ -306,7 +315,10 @@ public:
 private:
     // The insertion histogram: count the recorded insertions per column on the GPU, pick the columns
     // that matter, fetch their (column, string) records and add them up.
-    void CollectInsertions(msq_ctx* ctx, const msq_packed_reads* view, int32_t b0, InsertionMode mode)
+    /// basesOf(read, first, len): the literal nucleotide chars of ArrayBases [first, first + len) of a read -- asked
+    /// for the few runs the packed 2-bit form cannot hold (longer than 64 bases, or with a non-ACGT base).
+    void CollectInsertions(msq_ctx* ctx, const msq_packed_reads* view, int32_t b0, InsertionMode mode,
+                           const std::function<std::string(uint64_t, uint32_t, uint32_t)>& basesOf)
     {
         insertions_.assign((size_t)width_, {});
         if (width_ == 0) return;
@@ -336,8 +348,12 @@ private:
         std::string s;
         for (uint64_t k = 0; k < n; ++k) {
             const msq_insertion& r = records[k];
-            s.assign(r.len, 'A');
-            for (uint32_t i = 0; i < r.len; ++i) s[i] = nt[((i < 32 ? r.seq_lo >> (2 * i) : r.seq_hi >> (2 * (i - 32)))) & 3];
+            if (r.len > 64 || (view->flags & MSQ_READS_INS_EXOTIC)) {
+                s = basesOf(r.read, r.first_base, r.len);  // any length, literal chars (src/MSA.cpp:151-156,172-174)
+            } else {
+                s.assign(r.len, 'A');
+                for (uint32_t i = 0; i < r.len; ++i) s[i] = nt[((i < 32 ? r.seq_lo >> (2 * i) : r.seq_hi >> (2 * (i - 32)))) & 3];
+            }
             ++insertions_[(size_t)r.col][s];
         }
     }
@@ -374,31 +390,23 @@ private:
         // "Unexpected cigar ..." -> std::runtime_error
         // the insertion scan needs the genomic order inside each group (plain layout); the pileup takes both
         const uint32_t packFlags = insertionMode == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
-        Msq::Check(msq_pack_reads_device(ctx, reads.size(), rs.data(), re.data(), ptr.data(), len.data(), packFlags, 0, 0, &dev));
-        Finish(dev, reads.empty(), qv, insertionMode);
+        const msq_qv_thresholds thr{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};  // applied while packing, as above
+        Msq::Check(msq_pack_reads_device_baked(ctx, reads.size(), rs.data(), re.data(), ptr.data(), len.data(), packFlags, 0, 0, &thr, &dev));
+        Finish(dev, reads.empty(), qv, insertionMode, [&reads](uint64_t read, uint32_t first, uint32_t len) {
+            std::string s(len, 'A');
+            for (uint32_t i = 0; i < len; ++i) s[i] = reads[read]->Bases()[first + i].Nucleotide;
+            return s;
+        });
     }
 
     // window bounds, pileup and (on request) the insertion histogram of the packed reads now resident in HBM
-    void Finish(msq_packed_dev* dev, bool noReads, const QvThresholds& qv, InsertionMode insertionMode)
+    void Finish(msq_packed_dev* dev, bool noReads, const QvThresholds& qv, InsertionMode insertionMode,
+                const std::function<std::string(uint64_t, uint32_t, uint32_t)>& basesOf)
     {
         struct EmptyTag { bool empty() const { return value; } bool value; } reads{noReads};
         msq_ctx* ctx = Msq::Context();
         dev_.reset(dev, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // kept for PhaseKeys
         thr_ = msq_qv_thresholds{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
-        {
-            // The thresholds are fixed for the life of the MSA: apply them once (failing match bases become the 'N'
-            // AddRead writes, src/MSA.cpp:165-166) and let the QV planes go -- the pileup, the phasing gather and
-            // every later pass then stream 0.5 bytes per base.
-            const msq_packed_reads* v = msq_packed_dev_view(dev);
-            const bool masks = (thr_.qual >= 0 && v->qual) || (thr_.del >= 0 && v->delqv) || (thr_.sub >= 0 && v->subqv) ||
-                               (thr_.ins >= 0 && v->insqv);
-            if (masks) {
-                msq_packed_dev* baked = nullptr;
-                Msq::Check(msq_reads_bake_qv(ctx, v, &thr_, &baked));
-                dev_.reset(baked, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // frees the source
-                dev = baked;
-            }
-        }
         {
             int32_t b0 = 0, e0 = 0;
             Msq::Check(msq_window_bounds(ctx, msq_packed_dev_view(dev), &b0, &e0));
@@ -411,7 +419,7 @@ private:
             Msq::Check(msq_pileup_check(ctx));  // "Unexpected base ..." -> std::runtime_error
             nuc_ = dNuc_->ToHost();
             codon_ = dCodon_->ToHost();
-            if (insertionMode != InsertionMode::None) CollectInsertions(ctx, msq_packed_dev_view(dev), b0, insertionMode);
+            if (insertionMode != InsertionMode::None) CollectInsertions(ctx, msq_packed_dev_view(dev), b0, insertionMode, basesOf);
         }
         if (!reads.empty()) {  // ++beginPos_, ++endPos_ (src/MSA.cpp:107-108)
             ++beginPos_;

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void insertion_scan_kernel(const int32_t* __re
                                                              const uint4* __restrict__ bop, uint64_t n_reads, int32_t win_begin0, int32_t W,
                                                              int mode, uint32_t* __restrict__ counts, const uint32_t* __restrict__ filter,
                                                              msq_insertion* __restrict__ out, uint64_t capacity,
-                                                             unsigned long long* __restrict__ n_out /* [0] records, [1] too long */)
+                                                             unsigned long long* __restrict__ n_out /* [0] records */)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -139,17 +139,15 @@ __global__ __launch_bounds__(256) void insertion_scan_kernel(const int32_t* __re
                             hi |= code << (2 * (len - 32));
                     }
                 }
-                if (len > 64) {
-                    atomicAdd(&n_out[1], 1ull);
-                    continue;
-                }
                 const unsigned long long at = atomicAdd(&n_out[0], 1ull);
                 if (at < capacity) {
                     msq_insertion rec;
                     rec.col = col;
-                    rec.len = len;
+                    rec.len = len;  // beyond 64 bases the caller rebuilds the string from the read (read, first_base)
                     rec.seq_lo = lo;
                     rec.seq_hi = hi;
+                    rec.read = (uint32_t)r;
+                    rec.first_base = (uint32_t)((gs - g_begin) * 32 + (uint64_t)bs);  // plain layout: base k of a group in slot k
                     out[at] = rec;
                 }
             }
@@ -209,7 +207,6 @@ extern "C" int msq_insertion_records(msq_ctx* ctx, const msq_packed_reads* d_rea
     MSQ_HIP(hipMemcpyAsync(res, scratch, sizeof(res), hipMemcpyDeviceToHost, ctx->stream));
     MSQ_HIP(hipStreamSynchronize(ctx->stream));
     *n_out = res[0];
-    if (res[1]) return msq_fail(MSQ_ERR_RANGE, "msq_insertion_records: %llu insertions longer than 64 bases", res[1]);
     if (res[0] > capacity) return msq_fail(MSQ_ERR_RANGE, "msq_insertion_records: %llu records, capacity %llu", res[0], (unsigned long long)capacity);
     return MSQ_OK;
 }

@@ -19,7 +19,7 @@ struct msq_packed_host {
 
 // Per-base translation of (ArrayBase::Cigar, ArrayBase::Nucleotide) as MSAByRow::AddRead switches on
 // them (src/MSA.cpp:158-184).  Returns false on an unknown cigar char ("Unexpected cigar", :182).
-static inline __host__ __device__ bool encode_base(char cigar, char nuc, unsigned* op, unsigned* code, bool* exotic)
+static inline __host__ __device__ bool encode_base(char cigar, char nuc, unsigned* op, unsigned* code, bool* exotic, bool* ins_exotic)
 {
     switch (cigar) {
         case '=':
@@ -39,6 +39,7 @@ static inline __host__ __device__ bool encode_base(char cigar, char nuc, unsigne
             *op = 2;
             // inserted bases never reach a count matrix; keep the 2-bit code when it is one
             *code = nuc == 'C' ? 1 : nuc == 'G' ? 2 : nuc == 'T' ? 3 : 0;
+            if (*code == 0 && nuc != 'A') *ins_exotic = true;  // the insertion string keeps the literal char (MSA.cpp:172-174)
             return true;
         case 'P':
         case 'S':
@@ -78,7 +79,7 @@ extern "C" int msq_pack_reads(uint64_t n_reads, const int32_t* ref_start, const 
         std::vector<uint8_t>* dst[4] = {&p->qual, &p->delqv, &p->subqv, &p->insqv};
         for (int k = 0; k < 4; ++k)
             if (src[k]) dst[k]->assign(g * 32, 0);
-        bool exotic = false;
+        bool exotic = false, ins_exotic = false;
         for (uint64_t r = 0; r < n_reads; ++r) {
             const int64_t b0 = base_off[r], len = base_off[r + 1] - b0;
             const uint64_t g0 = p->group_off[r], ng = p->group_off[r + 1] - g0;
@@ -91,7 +92,7 @@ extern "C" int msq_pack_reads(uint64_t n_reads, const int32_t* ref_start, const 
                     slot[k] = -1;
                     if (i >= len) break;
                     unsigned op = 3, code = 0;
-                    if (!encode_base(cigar[b0 + i], nuc[b0 + i], &op, &code, &exotic)) {
+                    if (!encode_base(cigar[b0 + i], nuc[b0 + i], &op, &code, &exotic, &ins_exotic)) {
                         const int bad = (unsigned char)cigar[b0 + i];
                         delete p;
                         // std::runtime_error("Unexpected cigar " + std::to_string(b.Cigar)), src/MSA.cpp:182
@@ -127,7 +128,7 @@ extern "C" int msq_pack_reads(uint64_t n_reads, const int32_t* ref_start, const 
         v.delqv = delqv ? p->delqv.data() : nullptr;
         v.subqv = subqv ? p->subqv.data() : nullptr;
         v.insqv = insqv ? p->insqv.data() : nullptr;
-        v.flags = (exotic ? MSQ_READS_HAS_EXOTIC : 0u) | MSQ_READS_NORMALIZED;
+        v.flags = (exotic ? MSQ_READS_HAS_EXOTIC : 0u) | (ins_exotic ? MSQ_READS_INS_EXOTIC : 0u) | MSQ_READS_NORMALIZED;
         v.reserved = 0;
     } catch (const std::bad_alloc&) {
         delete p;
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(const uint64_t* __rest
                                                           uint64_t r0, uint64_t r1, uint64_t g0, uint64_t g1, uint4* __restrict__ bop,
                                                           uint8_t* __restrict__ q_qual, uint8_t* __restrict__ q_del,
                                                           uint8_t* __restrict__ q_sub, uint8_t* __restrict__ q_ins,
-                                                          unsigned long long* __restrict__ err, uint32_t* __restrict__ flags, int plain)
+                                                          unsigned long long* __restrict__ err, uint32_t* __restrict__ flags, int plain,
+                                                          int bake, msq_qv_thresholds thr)
 {
     __shared__ uint8_t nib[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, k = lane & 31;
@@ -223,13 +225,27 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(const uint64_t* __rest
     const bool has = valid_g && i < len;
     const uint64_t w = has ? stage[b0 - chunk_base0 + i] : 0;  // {Cigar, Nucleotide, HasQualQV, HasRichQVs, QualQV, DelQV, SubQV, InsQV}
     unsigned op = 3, code = 0;
-    bool exotic = false;
-    if (has && !encode_base((char)(w & 0xff), (char)((w >> 8) & 0xff), &op, &code, &exotic)) {
+    bool exotic = false, ins_exotic = false;
+    if (has && !encode_base((char)(w & 0xff), (char)((w >> 8) & 0xff), &op, &code, &exotic, &ins_exotic)) {
         atomicMin(err, (unsigned long long)(((b0 + i) << 8) | (w & 0xff)));  // the first one in read order is reported
         op = 3;
         code = 0;
     }
     if (exotic) atomicOr(flags, MSQ_READS_HAS_EXOTIC);
+    if (ins_exotic) atomicOr(flags, MSQ_READS_INS_EXOTIC);
+    if (bake && has) {
+        // the thresholds applied while packing (what msq_reads_bake_qv does to a packed set): a '=' / 'X' base -- op 0,
+        // or one of the exotic match bases under op 1, codes 2 and 3 -- that misses a threshold becomes the literal 'N'
+        // MSAByRow::AddRead writes for it (src/MSA.cpp:163-166); an absent QV passes (ArrayRead.inl:72-87)
+        const bool hq = (w >> 16) & 0xff, hr = (w >> 24) & 0xff;
+        const int qq = (int)((w >> 32) & 0xff), qd = (int)((w >> 40) & 0xff), qs = (int)((w >> 48) & 0xff), qi = (int)((w >> 56) & 0xff);
+        const bool pass = (thr.qual < 0 || !hq || qq >= thr.qual) && (thr.del < 0 || !hr || qd >= thr.del) &&
+                          (thr.sub < 0 || !hr || qs >= thr.sub) && (thr.ins < 0 || !hr || qi >= thr.ins);
+        if (!pass && (op == 0 || (op == 1 && code >= 2))) {
+            op = 1;
+            code = 1;
+        }
+    }
     // normalized layout: consuming bases from slot 0 up, the others from 31 down, both in genomic order;
     // plain layout (MSQ_PACK_PLAIN): base k in slot k, padding marked with nucleotide code 3
     const bool cons = has && op < 2, ncons = has && op >= 2;
@@ -287,7 +303,8 @@ static uint64_t stage_read(uint64_t* dst, uint64_t r, const msq_array_base* cons
 
 static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
                                   const msq_array_base* const* bases, const int64_t* n_bases, msq_fill_read_fn fill,
-                                  void* user, uint32_t pack_flags, int threads, int64_t chunk_bases, msq_packed_dev** out)
+                                  void* user, uint32_t pack_flags, int threads, int64_t chunk_bases, const msq_qv_thresholds* bake_thr,
+                                  msq_packed_dev** out)
 {
     static_assert(sizeof(msq_array_base) == 8, "msq_array_base is one 8-byte record");
     if (!ctx || !out) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL argument");
@@ -295,6 +312,15 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
     if (n_reads && (!ref_start || !ref_end || (!bases && !fill) || !n_bases)) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL array");
     if (pack_flags & ~MSQ_PACK_PLAIN) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: unknown pack flag");
     const int plain = (pack_flags & MSQ_PACK_PLAIN) ? 1 : 0;
+    msq_qv_thresholds thr{-1, -1, -1, -1};
+    if (bake_thr) {
+        thr = *bake_thr;
+        for (int k = 0; k < 4; ++k) {
+            const int32_t t = (&thr.qual)[k];
+            if (t < -1 || t > 255) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: QV threshold %d out of range", t);
+        }
+    }
+    uint64_t any_all = 0;  // OR of every record of the set: which QVs any base carries
     MSQ_HIP(hipSetDevice(ctx->device));
     std::vector<uint64_t> base_off, group_off;
     int64_t longest = 0;
@@ -409,10 +435,12 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
             }
             for (unsigned t = 0; t < workers; ++t) any |= ors[t];
         }
-        // QV planes appear with the first chunk that carries the QV; every base before it lacked it -> 255
+        any_all |= any;
+        // QV planes appear with the first chunk that carries the QV; every base before it lacked it -> 255.  With the
+        // thresholds applied here no plane is written at all.
         const bool want[4] = {((any >> 16) & 0xff) != 0, ((any >> 24) & 0xff) != 0, ((any >> 24) & 0xff) != 0, ((any >> 24) & 0xff) != 0};
         for (int q = 0; q < 4; ++q)
-            if (want[q] && !d->ptrs[4 + q]) {
+            if (!bake_thr && want[q] && !d->ptrs[4 + q]) {
                 hipError_t e = hipMalloc(&d->ptrs[4 + q], n_groups * 32 ? n_groups * 32 : 16);
                 if (e == hipSuccess && group_off[r0]) e = hipMemsetAsync(d->ptrs[4 + q], 0xFF, group_off[r0] * 32, ctx->stream);
                 if (e == hipSuccess && n_groups > group_off[r0])
@@ -427,7 +455,8 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
             const uint64_t blocks = (g1 - g0 + 7) / 8;  // 4 waves x 2 groups
             hipLaunchKernelGGL(pack_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_stage, base_off[r0],
                                (const uint64_t*)d_base_off, (const uint64_t*)d->ptrs[2], r0, r1, g0, g1, (uint4*)d->ptrs[3],
-                               (uint8_t*)d->ptrs[4], (uint8_t*)d->ptrs[5], (uint8_t*)d->ptrs[6], (uint8_t*)d->ptrs[7], d_errword, d_flags, plain);
+                               (uint8_t*)d->ptrs[4], (uint8_t*)d->ptrs[5], (uint8_t*)d->ptrs[6], (uint8_t*)d->ptrs[7], d_errword, d_flags, plain,
+                               bake_thr ? 1 : 0, thr);
             e = hipGetLastError();
             if (e != hipSuccess) return fail(MSQ_ERR_HIP, "pack kernel", e);
         } else {
@@ -460,7 +489,11 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
     v.delqv = (const uint8_t*)d->ptrs[5];
     v.subqv = (const uint8_t*)d->ptrs[6];
     v.insqv = (const uint8_t*)d->ptrs[7];
-    v.flags = ((uint32_t)res[1] & MSQ_READS_HAS_EXOTIC) | (plain ? MSQ_READS_PAD_MARKED : MSQ_READS_NORMALIZED);
+    v.flags = ((uint32_t)res[1] & (MSQ_READS_HAS_EXOTIC | MSQ_READS_INS_EXOTIC)) | (plain ? MSQ_READS_PAD_MARKED : MSQ_READS_NORMALIZED);
+    if (bake_thr) {  // as msq_reads_bake_qv flags its result: a threshold met a QV some base carries
+        const bool has_q = ((any_all >> 16) & 0xff) != 0, has_r = ((any_all >> 24) & 0xff) != 0;
+        if ((thr.qual >= 0 && has_q) || (has_r && (thr.del >= 0 || thr.sub >= 0 || thr.ins >= 0))) v.flags |= MSQ_READS_QV_BAKED;
+    }
     v.reserved = 0;
     *out = d;
     return MSQ_OK;
@@ -471,7 +504,16 @@ extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32
                                      int threads, int64_t chunk_bases, msq_packed_dev** out)
 {
     if (n_reads && !bases) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL array");
-    return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, bases, n_bases, nullptr, nullptr, pack_flags, threads, chunk_bases, out);
+    return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, bases, n_bases, nullptr, nullptr, pack_flags, threads, chunk_bases, nullptr, out);
+}
+
+extern "C" int msq_pack_reads_device_baked(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                           const msq_array_base* const* bases, const int64_t* n_bases, uint32_t pack_flags,
+                                           int threads, int64_t chunk_bases, const msq_qv_thresholds* thr, msq_packed_dev** out)
+{
+    if (n_reads && !bases) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device_baked: NULL array");
+    if (!thr) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device_baked: thr is NULL");
+    return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, bases, n_bases, nullptr, nullptr, pack_flags, threads, chunk_bases, thr, out);
 }
 
 extern "C" int msq_pack_reads_device_fill(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
@@ -479,5 +521,14 @@ extern "C" int msq_pack_reads_device_fill(msq_ctx* ctx, uint64_t n_reads, const 
                                           int threads, int64_t chunk_bases, msq_packed_dev** out)
 {
     if (!fill) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device_fill: fill is NULL");
-    return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, nullptr, n_bases, fill, user, pack_flags, threads, chunk_bases, out);
+    return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, nullptr, n_bases, fill, user, pack_flags, threads, chunk_bases, nullptr, out);
+}
+
+extern "C" int msq_pack_reads_device_fill_baked(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                                const int64_t* n_bases, msq_fill_read_fn fill, void* user, uint32_t pack_flags,
+                                                int threads, int64_t chunk_bases, const msq_qv_thresholds* thr, msq_packed_dev** out)
+{
+    if (!fill) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device_fill_baked: fill is NULL");
+    if (!thr) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device_fill_baked: thr is NULL");
+    return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, nullptr, n_bases, fill, user, pack_flags, threads, chunk_bases, thr, out);
 }

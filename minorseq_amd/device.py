@@ -80,10 +80,10 @@ def pack_host(reads):
     return out
 
 
-def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases=0, plain=False):
+def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases=0, plain=False, thr=None):
     """msq_pack_reads_device on unpacked reads (the dict pack_host takes) -> the packed arrays copied back from HBM,
     in pack_host()'s layout.  has_qual / has_rich: per-base presence bytes (default: present wherever the dict
-    holds the QV array)."""
+    holds the QV array).  thr: msq_pack_reads_device_baked with these thresholds instead."""
     L = abi.lib()
     n = int(reads["n_reads"])
     off = np.asarray(reads["base_off"], dtype=np.int64)
@@ -102,8 +102,12 @@ def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases
     ptrs = (rec.ctypes.data + off[:-1] * 8).astype(np.uint64)
     lens = np.diff(off).astype(np.int64)
     h = C.c_void_p()
-    abi.check(L.msq_pack_reads_device(ctx.h, n, abi.ptr(reads["ref_start"]), abi.ptr(reads["ref_end"]), abi.ptr(ptrs), abi.ptr(lens),
-                                      abi.MSQ_PACK_PLAIN if plain else 0, threads, chunk_bases, C.byref(h)))
+    if thr is None:
+        abi.check(L.msq_pack_reads_device(ctx.h, n, abi.ptr(reads["ref_start"]), abi.ptr(reads["ref_end"]), abi.ptr(ptrs), abi.ptr(lens),
+                                          abi.MSQ_PACK_PLAIN if plain else 0, threads, chunk_bases, C.byref(h)))
+    else:
+        abi.check(L.msq_pack_reads_device_baked(ctx.h, n, abi.ptr(reads["ref_start"]), abi.ptr(reads["ref_end"]), abi.ptr(ptrs),
+                                                abi.ptr(lens), abi.MSQ_PACK_PLAIN if plain else 0, threads, chunk_bases, thr, C.byref(h)))
     try:
         v = L.msq_packed_dev_view(h).contents
         g = int(v.n_groups)
@@ -348,8 +352,11 @@ def insertion_counts(ctx, dr, win_begin0, W):
     return counts.cpu().numpy()[:W].astype(np.int64)
 
 
-def insertion_records(ctx, dr, win_begin0, W, cols=None, capacity=None):
-    """msq_insertion_records -> list of (col, string); cols = iterable of window columns to keep (None = all)."""
+def insertion_records(ctx, dr, win_begin0, W, cols=None, capacity=None, reads=None):
+    """msq_insertion_records -> list of (col, string); cols = iterable of window columns to keep (None = all).
+    reads: the unpacked reads the set was packed from; with them a run longer than 64 bases, or any run of a set
+    flagged MSQ_READS_INS_EXOTIC, is rebuilt from the read's own bases (record.read / record.first_base), as the
+    C++ front does; without them only the 2-bit prefix of such a run is returned."""
     filt = None
     if cols is not None:
         bits = np.zeros((W + 31) // 32 + 1, dtype=np.uint32)
@@ -358,18 +365,26 @@ def insertion_records(ctx, dr, win_begin0, W, cols=None, capacity=None):
         filt = torch.from_numpy(bits.view(np.int32)).cuda()
     if capacity is None:
         capacity = int(insertion_counts(ctx, dr, win_begin0, W).sum())
-    rec = torch.zeros(max(capacity, 1) * 3, dtype=torch.int64, device="cuda")  # msq_insertion = 24 bytes
+    rec = torch.zeros(max(capacity, 1) * 4, dtype=torch.int64, device="cuda")  # msq_insertion = 32 bytes
     n = C.c_uint64(0)
     abi.check(abi.lib().msq_insertion_records(ctx.h, dr.view, win_begin0, W, None if filt is None else filt.data_ptr(),
                                               rec.data_ptr(), capacity, C.byref(n)))
-    raw = rec.cpu().numpy()[:n.value * 3].reshape(-1, 3)
+    raw = rec.cpu().numpy()[:n.value * 4].reshape(-1, 4)
     out = []
-    for head, lo, hi in raw:
+    for head, lo, hi, loc in raw:
         col, ln = int(head & 0xFFFFFFFF), int((head >> 32) & 0xFFFFFFFF)
         if col >= 1 << 31:
             col -= 1 << 32
         bits = (int(lo) & 0xFFFFFFFFFFFFFFFF) | ((int(hi) & 0xFFFFFFFFFFFFFFFF) << 64)
-        out.append((col, "".join("ACGT"[(bits >> (2 * k)) & 3] for k in range(ln))))
+        s = "".join("ACGT"[(bits >> (2 * k)) & 3] for k in range(min(ln, 64)))
+        if reads is not None and (ln > 64 or dr.flags & abi.MSQ_READS_INS_EXOTIC):
+            r, first = int(loc & 0xFFFFFFFF), int((loc >> 32) & 0xFFFFFFFF)
+            at = int(reads["base_off"][r]) + first
+            assert bytes(reads["cigar"][at:at + ln]) == b"I" * ln
+            whole = bytes(reads["nuc"][at:at + ln]).decode()
+            assert "".join(c if c in "ACGT" else "A" for c in whole[:64]) == s  # the packed prefix is the same run
+            s = whole
+        out.append((col, s))
     return out
 
 

@@ -164,6 +164,35 @@ int main()
         c.MaximalPerc = 90;
         Juliet::AminoAcidCaller aac4(reads, error, c);
         Dump("debug_maxperc90", aac4);
+
+        // expected minors (an HIV-PB-style configuration): MeasurePerformance's predictor logic and the store
+        // branches that depend on it (src/AminoAcidCaller.cpp:341-378, 519-539).  The configured reference differs
+        // from the sample in two codons of geneA (amino acids 5 and 7), so the sample's own majority codon is tested
+        // there at a frequency above 0.8: listed as an expected minor it is a predictor at a non-variable site
+        // (stored, a true positive), unlisted it is neither and must NOT be stored.  The planted 8 % clone gives a
+        // predictor at a variable site (amino acid 11) and variable non-predictors (amino acid 21, geneB); a
+        // one-substitution neighbour seen a few times is a predictor that stays insignificant (false negative).
+        Juliet::JulietSettings e;
+        e.TargetConfigUser = c.TargetConfigUser;
+        std::string fullx = full;
+        auto other = [](char ch) { return ch == 'A' ? 'C' : 'A'; };
+        fullx[start0 + 12] = other(fullx[start0 + 12]);  // amino acid 5 of geneA: window columns 12..14
+        fullx[start0 + 19] = other(fullx[start0 + 19]);  // amino acid 7: columns 18..20
+        e.TargetConfigUser.referenceSequence = fullx;
+        std::string clone11 = ref.substr(30, 3), noise15 = ref.substr(42, 3);
+        clone11[1] = clone11[1] == 'A' ? 'G' : 'A';       // the clone's change at column 31 (MakeReads)
+        noise15[1] = noise15[1] == 'C' ? 'T' : 'C';       // the 'X' substitution MakeReads writes at column 43
+        const std::string major7 = ref.substr(18, 3);
+        auto minor = [](int pos, const std::string& codon) {
+            return Juliet::ExpectedMinor{pos, std::string(1, Juliet::AminoAcidTable::At(codon)), codon};
+        };
+        e.TargetConfigUser.targetGenes[0].minors = {minor(11, clone11), minor(7, major7), minor(15, noise15), minor(30, "AAA")};
+        std::printf("REFX %s\n", fullx.c_str());
+        for (const auto& m : e.TargetConfigUser.targetGenes[0].minors)
+            std::printf("MINOR geneA %d %s %s\n", m.position, m.aminoacid.c_str(), m.codon.c_str());
+        Juliet::AminoAcidCaller aac5(reads, error, e);
+        Dump("expectedminors", aac5);
+        DumpReports("expectedminors", aac5);
     }
     {
         std::printf("READS rich\n");
@@ -198,6 +227,9 @@ int main()
                 if (c == 200 && urand() < 0.9) insert("AC");
                 if (c == 250 && urand() < 0.4) insert("CAT");
                 if (c == 280 && urand() < 0.7) insert(urand() < 0.5 ? "AAA" : "AAC");
+                // strings the packed 2-bit form cannot hold: 69 bases, and a non-ACGT char (src/MSA.cpp:151-156,172-174)
+                if (c == 150 && r % 40 == 3) insert("ACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTTGCAACGTT");
+                if (c == 160 && r % 40 == 5) insert("GNT");
                 if (c > a && urand() < 0.01) insert(urand() < 0.5 ? "G" : "TCA");
                 if (c == 50 && urand() < 0.7)
                     bases.emplace_back('D', '-', (uint8_t)0);

@@ -245,6 +245,42 @@ def test_empty_and_broken_files(tmp_path, ref):
     assert rc == 1 and "cannot open" in rest[0]
 
 
+def test_crafted_bgzf_and_bam_headers_are_refused(tmp_path, ref):
+    """Nothing in a BGZF / BAM header is trusted: an extra field or subfield that runs past the file, a BSIZE smaller
+    than the block's own header + trailer (the payload length would wrap), a block cut inside its payload, a reference
+    name length past the data -- each is a clean 'ERR', never a read outside the mapping."""
+    rng = np.random.default_rng(5)
+    good = str(tmp_path / "g.bam")
+    write_bam(good, make_records(rng, ref, 12), len(ref))
+    data = bytearray(open(good, "rb").read())
+    bad = str(tmp_path / "bad.bam")
+
+    def refused(blob, what):
+        open(bad, "wb").write(bytes(blob))
+        rc, got, rest = run_bam_test(bad, 0, INT_MAX)
+        assert rc == 1 and rest and rest[0].startswith("ERR "), what
+
+    d = bytearray(data)
+    d[10:12] = struct.pack("<H", 0xFFFF)           # XLEN far past the block (and, for a short file, past the file)
+    refused(d[:2000], "over-long xlen in a short file")
+    refused(d, "over-long xlen")
+    d = bytearray(data)
+    d[14:16] = struct.pack("<H", 0xFFF0)           # the BC subfield claims 65520 bytes
+    refused(d, "subfield past the extra field")
+    d = bytearray(data)
+    d[16:18] = struct.pack("<H", 10)               # BSIZE 11: smaller than header + trailer
+    refused(d, "bsize below the header size")
+    bsize = struct.unpack("<H", data[16:18])[0] + 1
+    refused(data[:bsize - 5], "block cut inside its trailer")
+    refused(data[:30], "block cut inside its payload")
+    # a reference name length that runs past the inflated data
+    text = b"@HD\tVN:1.5\n"
+    raw = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", 1) + struct.pack("<I", 0x7FFFFFF0) + b"ref\0"
+    refused(bgzf_block(raw) + bgzf_block(b""), "l_name past the data")
+    raw = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", 3) + struct.pack("<I", 4) + b"ref\0" + struct.pack("<I", 9)
+    refused(bgzf_block(raw) + bgzf_block(b""), "n_ref past the data")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rich", [False, True])
 def test_bam_to_counts_matches_oracle(tmp_path, ref, rich):

@@ -64,6 +64,37 @@ def test_baked_counts_equal_thresholded_counts(ctx, name, plain):
     baked.close()
 
 
+@pytest.mark.parametrize("plain", [False, True])
+@pytest.mark.parametrize("name", sorted(EDGE) + ["random_rich", "random_qual", "wide_rich", "high_thr", "some_absent"])
+def test_packer_applies_thresholds_like_pack_then_bake(ctx, name, plain):
+    """msq_pack_reads_device_baked == msq_pack_reads_device + msq_reads_bake_qv, byte for byte: tables, bit planes,
+    flags, no QV planes -- with one chunk and with many, with QVs present on some bases only."""
+    has_qual = has_rich = None
+    if name == "some_absent":
+        reads, thr = cases.random_reads(65, 150, 600, rich=True, p_ins=0.04), (50, 30, 42, 35)
+        rng = np.random.RandomState(65)
+        total = int(reads["base_off"][-1])
+        has_qual, has_rich = (rng.rand(total) < 0.7).astype(np.uint8), (rng.rand(total) < 0.5).astype(np.uint8)
+    else:
+        reads, thr = case(name)
+    q = abi.QvThresholds.make(*thr[:4])
+    src = device.upload(device.pack_device(ctx, reads, has_qual=has_qual, has_rich=has_rich, plain=plain), ctx.device)
+    want_set = device.bake_qv(ctx, src, q)
+    want = want_set.download()
+    for chunk_bases, threads in ((0, 0), (700, 3)):
+        got = device.pack_device(ctx, reads, has_qual=has_qual, has_rich=has_rich, plain=plain, thr=q, chunk_bases=chunk_bases, threads=threads)
+        assert got["flags"] == want["flags"], (got["flags"], want["flags"])
+        assert got["n_groups"] == want["n_groups"]
+        for f in ("qual", "delqv", "subqv", "insqv"):
+            assert got[f] is None
+        for f in ("ref_start", "ref_end", "group_off", "bop"):
+            assert (np.asarray(got[f]) == np.asarray(want[f])).all(), f
+    want_set.close()
+    with pytest.raises(abi.MsqError) as err:
+        device.pack_device(ctx, reads, thr=abi.QvThresholds.make(qual=256))
+    assert err.value.code == abi.MSQ_ERR_ARG
+
+
 @pytest.mark.parametrize("seed,W,thr", [(71, 2500, (40, -1, 42, -1)), (72, 5000, (35, 20, -1, 30))])
 def test_baked_phase_keys_and_partition(ctx, seed, W, thr):
     reads = cases.random_reads(seed, 200, W, rich=True, p_ins=0.03, p_del=0.03)

@@ -28,7 +28,7 @@ def dump():
         env.pop(k, None)
     out = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    d = {"fisher": {}, "reads": {}, "cases": {}, "err": [], "ref": None, "phase": {}}
+    d = {"fisher": {}, "reads": {}, "cases": {}, "err": [], "ref": None, "phase": {}, "refx": None, "minors": []}
     cur_reads = cur_case = cur_phase = None
     d["json"], d["msatable"], d["errmode"] = {}, {}, {}
     block = None  # (kind, name, lines) while inside a JSON / MSATABLE / ERRMODE block
@@ -68,6 +68,10 @@ def dump():
             d["fisher"][int(t[1])] = float(t[2])
         elif t[0] == "REF":
             d["ref"] = t[1]
+        elif t[0] == "REFX":
+            d["refx"] = t[1]
+        elif t[0] == "MINOR":
+            d["minors"].append((t[1], int(t[2]), t[3], t[4]))
         elif t[0] == "READS":
             cur_reads = d["reads"].setdefault(t[1], [])
             reads_name = t[1]
@@ -118,7 +122,8 @@ def test_fisher_equivalent_with_R(dump):
 
 GENES = {"noconfig": [], "rich_default_subqv42": [],
          "config": [("geneA", 41, 161), ("geneB", 102, 230)], "drmonly": [("geneA", 41, 161), ("geneB", 102, 230)],
-         "debug_maxperc90": [("geneA", 41, 161), ("geneB", 102, 230)]}
+         "debug_maxperc90": [("geneA", 41, 161), ("geneB", 102, 230)],
+         "expectedminors": [("geneA", 41, 161), ("geneB", 102, 230)]}
 
 
 def drm_string(gene, aa_pos):  # the DRM table of tests/cpp/front_test.cpp through FindDRMs (src/AminoAcidCaller.cpp:105-124)
@@ -148,6 +153,12 @@ def test_caller_matches_oracle(dump, case):
 
     genes = GENES[case]
     ref = dump["ref"] if genes else ""
+    minors = []
+    if case == "expectedminors":  # the configured reference differs from the sample in two codons; geneA lists minors
+        ref, minors = dump["refx"], dump["minors"]
+        assert len(minors) == 4 and ref != dump["ref"]
+    perf = {"TP": 0, "FP": 0, "FN": 0, "TN": 0}
+    kinds = set()
     debug = case == "debug_maxperc90"
     drm_only = case == "drmonly"
     max_perc = 90.0 if debug else 100.0
@@ -159,14 +170,26 @@ def test_caller_matches_oracle(dump, case):
         p = pos[oc.position]
         gene, aa_pos, coverage = names[p[0]], int(p[2]), int(p[4])
         aa = orc.lib().orc_amino_acid(oc.codon).decode()
+        # MeasurePerformance (src/AminoAcidCaller.cpp:341-378): predictor = an expected minor of this gene with this
+        # position, amino acid and codon; counted at variable sites (frequency < 0.8) and for predictors anywhere
+        predictor = any(mg == gene and mp == aa_pos and ma[0] == aa and mc == CODONS[oc.codon] for mg, mp, ma, mc in minors)
+        variable = oc.frequency < 0.8
+        sig = oc.p < ALPHA
+        if variable or predictor:
+            perf[("TP" if sig else "FN") if predictor else ("FP" if sig else "TN")] += 1
         store = False
         if debug:
             store = True
-        elif oc.p < ALPHA:
+        elif sig:
             if drm_only:
                 store = bool(drm_string(gene, aa_pos))
+            elif predictor:  # :529-537
+                store = True
+            elif minors:
+                store = variable
             else:
-                store = True  # no expected minors configured
+                store = True
+            kinds.add((predictor, variable, store))
         if store and (debug or oc.frequency * 100 >= 0.1):
             want_vars.append((gene, aa_pos, CODONS[p[5]], aa, CODONS[oc.codon], oc.frequency, oc.p, drm_string(gene, aa_pos) or "-", coverage))
     key = lambda v: (names.index(v[0]), v[1], v[3], CODONS.index(v[4]))
@@ -192,7 +215,18 @@ def test_caller_matches_oracle(dump, case):
         else:
             best = int(np.argmax(nuc[col]))
             assert wt == ("_" if best == 5 else "ACGT-"[best])
-    assert c["perf"][0] == 0  # no expected minors: nothing can be a true positive
+    assert c["perf"] == [perf["TP"], perf["FP"], perf["FN"], perf["TN"]]
+    if minors:
+        # every branch of the policy is taken: a predictor at a variable site and one at a non-variable site (stored),
+        # a variable non-predictor (stored), a significant non-variable non-predictor (the sample's majority codon
+        # against the altered reference: NOT stored), and a predictor that stays insignificant
+        assert {(True, True, True), (True, False, True), (False, True, True), (False, False, False)} <= kinds
+        assert perf["TP"] >= 2 and perf["FN"] >= 1 and perf["FP"] >= 2 and perf["TN"] > 100
+        stored = {(v[0], v[1], v[4]) for v in got_vars}
+        assert ("geneA", 11, minors[0][3]) in stored and ("geneA", 7, minors[1][3]) in stored
+        assert not any(v[0] == "geneA" and v[1] == 5 for v in got_vars)  # the unlisted majority codon at amino acid 5
+    else:
+        assert c["perf"][0] == 0  # no expected minors: nothing can be a true positive
 
 
 @pytest.mark.parametrize("case", ["noconfig", "config", "rich_default_subqv42"])

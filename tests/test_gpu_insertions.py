@@ -27,7 +27,7 @@ def device_histogram(ctx, reads, cols=None, chunk=0):
     W = e0 - b0
     counts = device.insertion_counts(ctx, dr, b0, W)
     hist = [collections.Counter() for _ in range(W)]
-    for col, s in device.insertion_records(ctx, dr, b0, W, cols=cols):
+    for col, s in device.insertion_records(ctx, dr, b0, W, cols=cols, reads=reads):
         hist[col][s] += 1
     return W, counts, hist, dr, b0
 
@@ -108,13 +108,36 @@ def test_long_runs_and_block_borders(ctx):
     check_against_oracle(ctx, reads, chunk=3000)
 
 
-def test_too_long_insertion_is_an_error(ctx):
-    reads = cases.make_reads([(0, "==" + "I" * 65 + "==", "AC" + "G" * 65 + "TT"), (0, "====", "ACGT")])
-    dr = device.upload(device.pack_device(ctx, reads, plain=True))
-    assert device.insertion_counts(ctx, dr, 0, 4).tolist() == [0, 0, 1, 0]
-    with pytest.raises(abi.MsqError) as e:
-        device.insertion_records(ctx, dr, 0, 4, capacity=8)
-    assert e.value.code == abi.MSQ_ERR_RANGE and "longer than 64" in str(e.value)
+def test_long_and_non_acgt_insertions_keep_the_reference_strings(ctx):
+    """The reference stores insertion strings of any length with their literal chars (src/MSA.cpp:151-156,172-174).
+    The packed planes hold 2 bits per inserted base and a record 64 bases: a longer run, or one with a non-ACGT base,
+    comes back with its place in the read (read, first_base) and is rebuilt from the read's own bases."""
+    import random
+    rnd = random.Random(9)
+    long65 = "".join(rnd.choice("ACGT") for _ in range(65))
+    long200 = "".join(rnd.choice("ACGT") for _ in range(200))
+    rows = [
+        (0, "==" + "I" * 65 + "==", "AC" + long65 + "TT"),
+        (0, "====", "ACGT"),
+        (0, "=" + "I" * 200 + "===", "A" + long200 + "CGT"),          # spans seven groups
+        (0, "==" + "I" * 64 + "==", "AC" + long65[:64] + "TT"),        # exactly 64: still fits the record
+        (0, "==III==", "ACGNTGT"),                                     # an 'N' inside an insertion
+        (1, "=" + "I" * 70 + "==", "C" + "N" * 70 + "GT"),
+    ]
+    reads = cases.make_reads(rows)
+    packed = device.pack_device(ctx, reads, plain=True)
+    assert packed["flags"] & abi.MSQ_READS_INS_EXOTIC
+    assert device.pack_host(reads)["flags"] & abi.MSQ_READS_INS_EXOTIC
+    m = orc.Msa(reads)
+    assert m.col_insertions(2) == {long65: 1, long65[:64]: 1, "GNT": 1, "N" * 70: 1} and m.col_insertions(1) == {long200: 1}
+    check_against_oracle(ctx, reads)
+    # without the reads only the packed prefix comes back, and nothing fails
+    dr = device.upload(packed)
+    got = sorted(device.insertion_records(ctx, dr, 0, 4))
+    assert (2, long65[:64]) in got and (1, long200[:64]) in got and (2, "GAT") in got
+    clean = cases.make_reads(rows[:4])
+    assert not device.pack_device(ctx, clean, plain=True)["flags"] & abi.MSQ_READS_INS_EXOTIC
+    check_against_oracle(ctx, clean)
 
 
 def test_column_filter_and_capacity(ctx):
