@@ -258,6 +258,21 @@ int msq_pileup_check(msq_ctx* ctx);
 int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
                      int32_t W, int32_t n_pos, const int32_t* pos, uint16_t* d_keys);
 
+/* The collapse of reads with identical codon tuples in AminoAcidCaller::PhaseVariants
+ * (src/AminoAcidCaller.cpp:162-196: every read is compared with the observations so far and joins the first equal
+ * one, or opens a new one) on the key rows msq_phase_codons left in device memory: a hash + sort + segment pass.
+ *   d_cluster_of [n_reads]   observation index of every read; observations are numbered in the order of their first
+ *                            read, exactly the order the reference opens them in
+ *   d_first_read [n_reads]   first read of observation j (j < *n_clusters)
+ *   d_count      [n_reads]   reads in observation j
+ *   d_rep_keys   [rep_capacity * n_pos] the key row of observation j (= of its first read); may be NULL
+ * The names of an observation, in the reference's order, are those of the reads r = 0, 1, ... with cluster_of[r] = j.
+ * Rows are compared in full, never by hash alone.  MSQ_ERR_RANGE: more observations than rep_capacity, or two
+ * different rows share a 64-bit hash (then the caller clusters on the host).  Synchronises. */
+int msq_phase_cluster(msq_ctx* ctx, const uint16_t* d_keys, uint64_t n_reads, int32_t n_pos, uint32_t* d_cluster_of,
+                      uint32_t* d_first_read, uint32_t* d_count, uint16_t* d_rep_keys, uint64_t rep_capacity,
+                      uint64_t* n_clusters);
+
 /* ------------------------------------------------------------------------------------- insertion histogram
  * The insertion strings MSAByRow::AddRead records per row (`row.Insertions[pos] = insertion`, src/MSA.cpp:151-156:
  * consecutive 'I' bases, stored at the window column of the op that follows them; a later run flushed at the same

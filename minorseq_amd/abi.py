@@ -131,6 +131,7 @@ _SIGNATURES = {
     "msq_comm_allreduce_counts": (C.c_int, [_P, _P, C.c_size_t]),
     "msq_comm_allreduce_step": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "msq_comm_allgather": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "msq_phase_cluster": (C.c_int, [_P, _P, C.c_uint64, C.c_int32, _P, _P, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "msq_timing_enable": (C.c_int, [_P, C.c_int32]),
     "msq_timing_read": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "msq_plan_create": (C.c_int, [_P, C.c_int32, _P, _P, C.c_char_p, C.c_int64, C.c_int32, C.c_int32, C.POINTER(_P)]),

@@ -88,10 +88,11 @@ public:
         if (p_) msq_dev_free(Context(), p_);
     }
     T* get() const { return p_; }
-    std::vector<T> ToHost() const
+    std::vector<T> ToHost() const { return ToHost(n_); }
+    std::vector<T> ToHost(size_t count) const  // the first `count` elements
     {
-        std::vector<T> h(n_);
-        if (n_) Check(msq_memcpy_d2h(Context(), h.data(), p_, n_ * sizeof(T)));
+        std::vector<T> h(std::min(count, n_));
+        if (!h.empty()) Check(msq_memcpy_d2h(Context(), h.data(), p_, h.size() * sizeof(T)));
         return h;
     }
 
@@ -109,6 +110,13 @@ inline int CodonIndex(const std::string& s)  // -1 unless a key of AminoAcidTabl
         idx = idx * 4 + t;
     }
     return idx;
+}
+/// {"key", value} pairs -> a JSON object
+inline JSON::Json Obj(std::initializer_list<std::pair<const char*, JSON::Json>> members)
+{
+    JSON::Json o;
+    for (const auto& m : members) o[m.first] = m.second;
+    return o;
 }
 inline std::string CodonString(int idx)
 {
@@ -295,10 +303,58 @@ public:
         std::vector<uint16_t> keys(numReads_ * pos.size());
         if (keys.empty()) return keys;
         Msq::DeviceBuffer<uint16_t> dKeys(keys.size());
-        Msq::Check(msq_phase_codons(Msq::Context(), msq_packed_dev_view(dev_.get()), &thr_, beginPos_ - 1, width_,
-                                    (int32_t)pos.size(), pos.data(), dKeys.get()));
-        Msq::Check(msq_pileup_check(Msq::Context()));
+        GatherKeys(pos, dKeys.get());
         return dKeys.ToHost();
+    }
+    /// The rows of the MSA grouped by their codons at the given positions: rows with equal CodonAt strings at every
+    /// position form one group; groups are numbered by their first row (the order in which the reference's pairwise
+    /// comparison opens its observations, src/AminoAcidCaller.cpp:162-196).  Gather and grouping run on the GPU
+    /// (msq_phase_codons, msq_phase_cluster); what comes back is one id per row and one key row per group.
+    struct RowGroups
+    {
+        size_t numPositions = 0;
+        std::vector<uint32_t> groupOfRow;  // [rows]
+        std::vector<uint32_t> firstRow;    // [groups]
+        std::vector<uint32_t> size;        // [groups]
+        std::vector<uint16_t> keys;        // [groups][numPositions]
+        size_t NumGroups() const { return firstRow.size(); }
+    };
+    RowGroups GroupRowsByCodons(const std::vector<int32_t>& pos) const
+    {
+        RowGroups g;
+        g.numPositions = pos.size();
+        if (numReads_ == 0) return g;
+        const size_t K = pos.size();
+        msq_ctx* ctx = Msq::Context();
+        Msq::DeviceBuffer<uint16_t> dKeys(numReads_ * K);
+        if (K) GatherKeys(pos, dKeys.get());
+        Msq::DeviceBuffer<uint32_t> dGroup(numReads_), dFirst(numReads_), dSize(numReads_);
+        Msq::DeviceBuffer<uint16_t> dRows(numReads_ * K);
+        uint64_t n = 0;
+        const int rc = msq_phase_cluster(ctx, dKeys.get(), numReads_, (int32_t)K, dGroup.get(), dFirst.get(), dSize.get(), dRows.get(), numReads_, &n);
+        if (rc == MSQ_ERR_RANGE) {  // two different key rows with one 64-bit hash: group on the host
+            const std::vector<uint16_t> keys = dKeys.ToHost();
+            std::unordered_map<std::string, uint32_t> seen;
+            g.groupOfRow.resize(numReads_);
+            for (size_t r = 0; r < numReads_; ++r) {
+                const std::string row(reinterpret_cast<const char*>(keys.data() + r * K), K * sizeof(uint16_t));
+                const auto at = seen.emplace(row, (uint32_t)g.firstRow.size());
+                if (at.second) {
+                    g.firstRow.push_back((uint32_t)r);
+                    g.size.push_back(0);
+                    g.keys.insert(g.keys.end(), keys.begin() + r * K, keys.begin() + (r + 1) * K);
+                }
+                g.groupOfRow[r] = at.first->second;
+                ++g.size[at.first->second];
+            }
+            return g;
+        }
+        Msq::Check(rc);
+        g.groupOfRow = dGroup.ToHost();
+        g.firstRow = dFirst.ToHost(n);
+        g.size = dSize.ToHost(n);
+        g.keys = dRows.ToHost(n * K);
+        return g;
     }
     /// The string MSARow::CodonAt returns for one key of PhaseKeys.
     static std::string KeyToCodon(uint16_t key)
@@ -313,6 +369,12 @@ public:
     }
 
 private:
+    void GatherKeys(const std::vector<int32_t>& pos, uint16_t* dKeys) const
+    {
+        Msq::Check(msq_phase_codons(Msq::Context(), msq_packed_dev_view(dev_.get()), &thr_, beginPos_ - 1, width_, (int32_t)pos.size(),
+                                    pos.data(), dKeys));
+        Msq::Check(msq_pileup_check(Msq::Context()));
+    }
     // The insertion histogram: count the recorded insertions per column on the GPU, pick the columns
     // that matter, fetch their (column, string) records and add them up.
     /// basesOf(read, first, len): the literal nucleotide chars of ArrayBases [first, first + len) of a read -- asked
@@ -555,12 +617,11 @@ class DMutation  // include/pacbio/juliet/TargetConfig.h:49-62, src/TargetConfig
 {
 public:
     DMutation(char refAA, int pos, char curAA) : refAA(refAA), pos(pos), curAA(curAA) {}
+    /// '*' on either side stands for any amino acid
     bool operator==(const DMutation& a) const
     {
-        if (a.pos != pos) return false;
-        if (a.curAA != '*' && curAA != '*' && a.curAA != curAA) return false;
-        if (a.refAA != '*' && refAA != '*' && a.refAA != refAA) return false;
-        return true;
+        const auto agree = [](char x, char y) { return x == '*' || y == '*' || x == y; };
+        return a.pos == pos && agree(a.curAA, curAA) && agree(a.refAA, refAA);
     }
     char refAA;
     int pos;
@@ -708,15 +769,22 @@ struct PerformanceMetrics  // include/pacbio/juliet/AminoAcidCaller.h:55-78
     double TruePositiveRate() const { return TruePositives / NumExpectedMinors; }
     double FalsePositiveRate() const { return FalsePositives / (NumberOfTests - NumExpectedMinors); }
     double Accuracy() const { return (TruePositives + TrueNegative) / (TruePositives + FalsePositives + FalseNegative + TrueNegative); }
-    std::string ToJson() const  // src/AminoAcidCaller.cpp:579-588 (ostream formatting of doubles: 6 significant digits)
+    /// the one-line validation record (the text of src/AminoAcidCaller.cpp:579-588: ostream formatting, 6 significant digits)
+    std::string ToJson() const
     {
-        std::stringstream ss;
-        ss << "{\"true_positive_rate\":" << TruePositiveRate() << ",";
-        ss << "\"false_positive_rate\":" << FalsePositiveRate() << ",";
-        ss << "\"num_tests\":" << NumberOfTests << ",";
-        ss << "\"num_false_positives\":" << FalsePositives << ",";
-        ss << "\"accuracy\":" << Accuracy() << "}";
-        return ss.str();
+        const std::pair<const char*, double> fields[] = {{"true_positive_rate", TruePositiveRate()},
+                                                         {"false_positive_rate", FalsePositiveRate()},
+                                                         {"num_tests", NumberOfTests},
+                                                         {"num_false_positives", FalsePositives},
+                                                         {"accuracy", Accuracy()}};
+        std::ostringstream text;
+        char lead = '{';
+        for (const auto& f : fields) {
+            text << lead << '"' << f.first << "\":" << f.second;
+            lead = ',';
+        }
+        text << '}';
+        return text.str();
     }
 };
 
@@ -756,58 +824,40 @@ struct VariantGene  // include/pacbio/juliet/VariantGene.h:49-81
     };
     std::map<int, std::shared_ptr<VariantPosition>> relPositionToVariant;
 
-    JSON::Json ToJson() const  // src/VariantGene.cpp:42-81
+    /// The gene's entry of the report.  Key names and nesting are the report format (src/VariantGene.cpp:42-81):
+    /// name, variant_positions[] of {ref_position, ref_codon, coverage, ref_amino_acid, variant_amino_acids[] of
+    /// {amino_acid, variant_codons[] of {codon, frequency, pValue, known_drm, haplotype_hit}}, msa[]}; positions and
+    /// amino acids without a stored codon are left out, and so is variant_positions when nothing is left.
+    JSON::Json ToJson() const
     {
         using JSON::Json;
-        Json root;
-        root["name"] = geneName;
+        const auto codonEntry = [](const VariantPosition::VariantCodon& vc) {
+            return Msq::Obj({{"codon", vc.codon}, {"frequency", vc.frequency}, {"pValue", vc.pValue}, {"known_drm", vc.knownDRM},
+                             {"haplotype_hit", vc.haplotypeHit}});
+        };
+        const auto columnEntry = [](const MsaCounts& m) {
+            return Msq::Obj({{"rel_pos", m.rel_pos}, {"abs_pos", m.abs_pos}, {"A", m.A}, {"C", m.C}, {"G", m.G}, {"T", m.T},
+                             {"-", m.gap}, {"N", m.N}, {"wt", m.wt}});
+        };
         std::vector<Json> positions;
-        for (const auto& pos_variant : relPositionToVariant) {
-            const VariantPosition& vp = *pos_variant.second;
-            if (vp.aminoAcidToCodons.empty()) continue;
-            Json jVarPos;
-            jVarPos["ref_position"] = pos_variant.first;
-            jVarPos["ref_codon"] = vp.refCodon;
-            jVarPos["coverage"] = vp.coverage;
-            jVarPos["ref_amino_acid"] = std::string(1, vp.refAminoAcid);
-            std::vector<Json> jVarAAs;
-            for (const auto& aa_varCodon : vp.aminoAcidToCodons) {
-                if (aa_varCodon.second.empty()) continue;
-                Json jVarAA;
-                jVarAA["amino_acid"] = std::string(1, aa_varCodon.first);
-                std::vector<Json> jCodons;
-                for (const auto& codon : aa_varCodon.second) {
-                    Json jCodon;
-                    jCodon["codon"] = codon.codon;
-                    jCodon["frequency"] = codon.frequency;
-                    jCodon["pValue"] = codon.pValue;
-                    jCodon["known_drm"] = codon.knownDRM;
-                    jCodon["haplotype_hit"] = codon.haplotypeHit;
-                    jCodons.push_back(jCodon);
-                }
-                jVarAA["variant_codons"] = jCodons;
-                jVarAAs.push_back(jVarAA);
+        for (const auto& entry : relPositionToVariant) {
+            const VariantPosition& vp = *entry.second;
+            if (!vp.IsVariant()) continue;
+            std::vector<Json> aminoAcids, context;
+            for (const auto& group : vp.aminoAcidToCodons) {
+                if (group.second.empty()) continue;
+                std::vector<Json> codons;
+                std::transform(group.second.begin(), group.second.end(), std::back_inserter(codons), codonEntry);
+                aminoAcids.push_back(Msq::Obj({{"amino_acid", std::string(1, group.first)}, {"variant_codons", codons}}));
             }
-            jVarPos["variant_amino_acids"] = jVarAAs;
-            std::vector<Json> jMsa;  // the objects of src/AminoAcidCaller.cpp:549-563
-            for (const auto& m : vp.msa) {
-                Json msaCounts;
-                msaCounts["rel_pos"] = m.rel_pos;
-                msaCounts["abs_pos"] = m.abs_pos;
-                msaCounts["A"] = m.A;
-                msaCounts["C"] = m.C;
-                msaCounts["G"] = m.G;
-                msaCounts["T"] = m.T;
-                msaCounts["-"] = m.gap;
-                msaCounts["N"] = m.N;
-                msaCounts["wt"] = m.wt;
-                jMsa.push_back(msaCounts);
-            }
-            jVarPos["msa"] = jMsa;
-            positions.push_back(jVarPos);
+            std::transform(vp.msa.begin(), vp.msa.end(), std::back_inserter(context), columnEntry);
+            positions.push_back(Msq::Obj({{"ref_position", entry.first}, {"ref_codon", vp.refCodon}, {"coverage", vp.coverage},
+                                          {"ref_amino_acid", std::string(1, vp.refAminoAcid)}, {"variant_amino_acids", aminoAcids},
+                                          {"msa", context}}));
         }
-        if (!positions.empty()) root["variant_positions"] = positions;
-        return root;
+        Json gene = Msq::Obj({{"name", geneName}});
+        if (!positions.empty()) gene["variant_positions"] = positions;
+        return gene;
     }
 };
 
@@ -821,54 +871,62 @@ enum class HaplotypeType : int  // include/pacbio/juliet/Haplotype.h:46-54
     OFFTARGET = 16
 };
 
-class Haplotype  // include/pacbio/juliet/Haplotype.h:56-126, internal/Haplotype.inl, src/Haplotype.cpp
+/// One observed combination of codons over the variant positions and the reads that carry it
+/// (include/pacbio/juliet/Haplotype.h:56-126).  The flags a codon's characters raise -- '-' a gap, 'N' a
+/// heteroduplex (masked) base, ' ' a read that does not cover the position (src/Haplotype.cpp:50-57) -- come from
+/// one table look-up per character.
+class Haplotype
 {
 public:
     Haplotype() = delete;
-    Haplotype(const std::string readName, const std::vector<std::string>& codons, const HaplotypeType& flag)
-        : readNames_({readName}), codons_(codons), numCodons_(codons_.size())
+    Haplotype(std::vector<std::string> readNames, std::vector<std::string> codons, const HaplotypeType& flag)
+        : readNames_(std::move(readNames)), codons_(std::move(codons)), flags_(static_cast<int>(flag))
     {
-        AddFlag(flag);
-        SetFlagsByCodons();
+        for (const std::string& codon : codons_)
+            for (const char c : codon) flags_ |= CharFlag(c);
     }
-    double Size() const { return readNames_.size() + softCollapses_; }
-    std::string ConcatCodons() const { return std::accumulate(codons_.begin(), codons_.end(), std::string("")); }
+    Haplotype(const std::string& readName, const std::vector<std::string>& codons, const HaplotypeType& flag)
+        : Haplotype(std::vector<std::string>{readName}, codons, flag)
+    {
+    }
+    double Size() const { return static_cast<double>(readNames_.size()) + softCollapses_; }
+    std::string ConcatCodons() const
+    {
+        std::string all;
+        for (const auto& c : codons_) all += c;
+        return all;
+    }
     const std::vector<std::string>& ReadNames() const { return readNames_; }
     const std::string& Codon(const int i) const { return codons_.at(i); }
-    size_t NumCodons() const { return numCodons_; }
+    size_t NumCodons() const { return codons_.size(); }
     int Flags() const { return flags_; }
     std::string Name() const { return name_; }
     double Frequency() const { return frequency_; }
-    void SetFlagsByCodons()  // src/Haplotype.cpp:50-57
-    {
-        for (const auto& c : codons_) {
-            if (c.find('-') != std::string::npos) AddFlag(HaplotypeType::WITH_GAP);
-            if (c.find('N') != std::string::npos) AddFlag(HaplotypeType::WITH_HETERODUPLEX);
-            if (c.find(' ') != std::string::npos) AddFlag(HaplotypeType::PARTIAL);
-        }
-    }
     void AddFlag(const HaplotypeType& flag) { flags_ |= static_cast<int>(flag); }
     void Frequency(const double& freq) { frequency_ = freq; }
     void AddReadName(const std::string& name) { readNames_.push_back(name); }
     void AddSoftReadCount(const double s) { softCollapses_ += s; }
     void Name(const std::string& name) { name_ = name; }
-    JSON::Json ToJson() const  // src/Haplotype.cpp:59-70
+    /// the haplotype's entry of the report (key names: src/Haplotype.cpp:59-70)
+    JSON::Json ToJson() const
     {
-        JSON::Json root;
-        root["name"] = name_;
-        root["reads_hard"] = readNames_.size();
-        root["reads_soft"] = Size();
-        root["frequency"] = frequency_;
-        root["read_names"] = readNames_;
-        root["codons"] = codons_;
-        return root;
+        return Msq::Obj({{"name", name_}, {"reads_hard", readNames_.size()}, {"reads_soft", Size()}, {"frequency", frequency_},
+                         {"read_names", readNames_}, {"codons", codons_}});
     }
 
 private:
+    static int CharFlag(char c)
+    {
+        switch (c) {
+            case '-': return static_cast<int>(HaplotypeType::WITH_GAP);
+            case 'N': return static_cast<int>(HaplotypeType::WITH_HETERODUPLEX);
+            case ' ': return static_cast<int>(HaplotypeType::PARTIAL);
+            default: return 0;
+        }
+    }
     std::string name_;
     std::vector<std::string> readNames_;
     std::vector<std::string> codons_;
-    size_t numCodons_;
     double softCollapses_ = 0;
     double frequency_ = 0;
     int flags_ = 0;
@@ -909,113 +967,96 @@ public:
     const PerformanceMetrics& Performance() const { return *pm_; }
     const Data::MSAByRow& Rows() const { return msaByRow_; }
 
-    /// Phase variants into haplotypes (src/AminoAcidCaller.cpp:126-323).  The per-read gather -- CodonAt at every
-    /// variant position for every row -- runs on the GPU over the packed reads still resident in HBM; collapsing
-    /// rows with identical codon tuples is a hash on the returned keys (the same partition, in the same
-    /// first-occurrence order, as the reference's pairwise comparison); flags, ordering and naming are the
-    /// reference's own statements.
+    /// Phase variants into haplotypes (src/AminoAcidCaller.cpp:126-323).
+    /// 1. The codon of every read at every variant position, and the grouping of reads with identical codons at all
+    ///    of them, run on the GPU over the packed reads still resident in HBM (MSAByRow::GroupRowsByCodons): the same
+    ///    partition, in the same first-occurrence order, as the reference's pairwise comparison (:149-196).
+    /// 2. A group is OFFTARGET when one of its codons is neither a reference codon nor a stored variant codon (:157),
+    ///    LOW_COV below ten reads (:204); its codons add the gap / heteroduplex / partial flags.  Unflagged groups are
+    ///    the reported haplotypes ("generators"), the others are only counted.
+    /// 3. Both lists are ordered with the reference's own two sorts -- ascending std::sort, then, for the reported
+    ///    ones, std::stable_sort under the reference's `>=` comparator (:215-230) -- applied to the group sizes in the
+    ///    same sequence of calls, so that ties fall exactly as they do there.
     void PhaseVariants()
     {
-        std::vector<std::pair<int, std::shared_ptr<VariantGene::VariantPosition>>> variantPositions;
-        for (const auto& vg : variantGenes_)
-            for (const auto& pos_vp : vg.relPositionToVariant)
-                if (pos_vp.second->IsVariant())
-                    variantPositions.emplace_back(std::make_pair(vg.geneOffset + pos_vp.first * 3, pos_vp.second));
-        const size_t K = variantPositions.size();
-        std::vector<int32_t> pos;
-        for (const auto& pos_var : variantPositions) pos.push_back(pos_var.first - msaByRow_.BeginPos() - 3);  // :154
-        const std::vector<uint16_t> keys = msaByRow_.PhaseKeys(pos);
+        struct Site { int begin1; VariantGene::VariantPosition* variant; };
+        std::vector<Site> sites;
+        for (const auto& gene : variantGenes_)
+            for (const auto& entry : gene.relPositionToVariant)
+                if (entry.second->IsVariant()) sites.push_back(Site{gene.geneOffset + entry.first * 3, entry.second.get()});
+        std::vector<int32_t> columns;
+        for (const Site& site : sites) columns.push_back(site.begin1 - msaByRow_.BeginPos() - 3);  // CodonAt's argument, :154
+        const Data::MSAByRow::RowGroups groups = msaByRow_.GroupRowsByCodons(columns);
+        const size_t K = sites.size(), G = groups.NumGroups();
+
+        // the reads of every group, in read order
+        std::vector<std::vector<std::string>> members(G);
+        for (size_t g = 0; g < G; ++g) members[g].reserve(groups.size[g]);
         const auto& names = msaByRow_.ReadNames();
+        for (size_t r = 0; r < groups.groupOfRow.size(); ++r) members[groups.groupOfRow[r]].push_back(names[r]);
 
-        std::vector<std::shared_ptr<Haplotype>> observations;
-        std::unordered_map<std::string, size_t> seen;  // key row -> index into observations
-        for (size_t r = 0; r < names.size(); ++r) {
-            const std::string keyRow(reinterpret_cast<const char*>(keys.data() + r * K), K * sizeof(uint16_t));
-            const auto it = seen.find(keyRow);
-            if (it != seen.end()) {
-                observations[it->second]->AddReadName(names[r]);
-                continue;
-            }
-            std::vector<std::string> codons;
-            HaplotypeType flag = HaplotypeType::REPORT;
+        std::vector<Haplotype> reported, counted;
+        for (size_t g = 0; g < G; ++g) {
+            std::vector<std::string> codons(K);
+            bool onTarget = true;
             for (size_t k = 0; k < K; ++k) {
-                codons.emplace_back(Data::MSAByRow::KeyToCodon(keys[r * K + k]));
-                if (!variantPositions[k].second->IsHit(codons.back())) flag = HaplotypeType::OFFTARGET;  // :157
+                codons[k] = Data::MSAByRow::KeyToCodon(groups.keys[g * K + k]);
+                onTarget = onTarget && sites[k].variant->IsHit(codons[k]);
             }
-            seen.emplace(keyRow, observations.size());
-            observations.emplace_back(std::make_shared<Haplotype>(names[r], codons, flag));
+            Haplotype h(std::move(members[g]), std::move(codons), onTarget ? HaplotypeType::REPORT : HaplotypeType::OFFTARGET);
+            if (h.Size() < 10) h.AddFlag(HaplotypeType::LOW_COV);
+            (h.Flags() == 0 ? reported : counted).push_back(std::move(h));
         }
+        const auto bySize = [](const Haplotype& a, const Haplotype& b) { return a.Size() < b.Size(); };
+        OrderAs(reported, [&](std::vector<size_t>& order) {
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bySize(reported[a], reported[b]); });
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return reported[a].Size() >= reported[b].Size(); });
+        });
+        OrderAs(counted, [&](std::vector<size_t>& order) {
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return bySize(counted[a], counted[b]); });
+        });
 
-        std::vector<std::shared_ptr<Haplotype>> generators, filtered;  // :198-209
-        for (auto& h : observations) {
-            if (h->Size() < 10) h->AddFlag(HaplotypeType::LOW_COV);
-            if (h->Flags() == 0)
-                generators.emplace_back(std::move(h));
-            else
-                filtered.emplace_back(std::move(h));
+        double reportedReads = 0;
+        for (const Haplotype& h : reported) reportedReads += h.Size();
+        const bool twoLetters = reported.size() > 26;  // A .. Z, else Aa, Ab, ... (:234-247)
+        for (size_t n = 0; n < reported.size(); ++n) {
+            Haplotype& h = reported[n];
+            h.Frequency(h.Size() / reportedReads);
+            h.Name(twoLetters ? std::string{static_cast<char>('A' + n / 26), static_cast<char>('a' + n % 26)}
+                              : std::string(1, static_cast<char>('A' + n)));
+            for (size_t k = 0; k < K; ++k)  // one more bit per stored codon: does this haplotype carry it? (:253-263)
+                for (auto& group : sites[k].variant->aminoAcidToCodons)
+                    for (auto& vc : group.second) vc.haplotypeHit.push_back(h.Codon((int)k) == vc.codon);
+            genCounts_ += static_cast<int>(h.ReadNames().size());
         }
-        auto HaplotypeComp = [](const std::shared_ptr<Haplotype>& a, const std::shared_ptr<Haplotype>& b) {
-            return a->Size() < b->Size();
-        };
-        std::sort(generators.begin(), generators.end(), HaplotypeComp);  // :215-216
-        std::sort(filtered.begin(), filtered.end(), HaplotypeComp);
-        double counts = 0;
-        for (auto& hn : generators) counts += hn->Size();
-        std::stable_sort(generators.begin(), generators.end(),  // :227-230, the reference's >= comparator as it stands
-                         [](const std::shared_ptr<Haplotype>& a, const std::shared_ptr<Haplotype>& b) {
-                             return a->Size() >= b->Size();
-                         });
-        static constexpr int alphabetSize = 26;
-        const bool doubleName = generators.size() > alphabetSize;
-        for (size_t genNumber = 0; genNumber < generators.size(); ++genNumber) {  // :234-270
-            auto& hn = generators.at(genNumber);
-            hn->Frequency(hn->Size() / counts);
-            if (doubleName)
-                hn->Name(std::string(1, 'A' + genNumber / alphabetSize) + std::string(1, 'a' + genNumber % alphabetSize));
-            else
-                hn->Name(std::string(1, 'A' + genNumber));
-            for (size_t i = 0; i < hn->NumCodons(); ++i)
-                for (auto& kv : variantPositions.at(i).second->aminoAcidToCodons)
-                    for (auto& vc : kv.second) vc.haplotypeHit.push_back(hn->Codon(i) == vc.codon);
-            reconstructedHaplotypes_.push_back(*hn);
+        for (const Haplotype& h : counted) {  // the read counts behind "haplotype_read_counts" (:286-310)
+            const int reads = static_cast<int>(h.ReadNames().size()), flags = h.Flags();
+            const auto has = [flags](HaplotypeType t) { return (flags & static_cast<int>(t)) != 0; };
+            if (has(HaplotypeType::WITH_GAP)) margWithGap_ += reads;
+            if (has(HaplotypeType::WITH_HETERODUPLEX)) margWithHetero_ += reads;
+            if (has(HaplotypeType::PARTIAL)) margPartial_ += reads;
+            if (has(HaplotypeType::OFFTARGET)) margOfftarget_ += reads;
+            if (flags == static_cast<int>(HaplotypeType::LOW_COV)) lowCov_ += reads;  // low coverage and nothing else
         }
-        for (auto& hn : generators) genCounts_ += hn->ReadNames().size();  // :286-290
-        std::map<int, int> filteredCounts;
-        for (auto& h : filtered) {
-            filteredCounts[h->Flags()] += h->ReadNames().size();
-            filteredHaplotypes_.emplace_back(*h);
-        }
-        for (const auto& kv : filteredCounts) {  // :301-310
-            if (kv.first & static_cast<int>(HaplotypeType::WITH_GAP)) margWithGap_ += kv.second;
-            if (kv.first & static_cast<int>(HaplotypeType::WITH_HETERODUPLEX)) margWithHetero_ += kv.second;
-            if (kv.first & static_cast<int>(HaplotypeType::PARTIAL)) margPartial_ += kv.second;
-            if (kv.first == static_cast<int>(HaplotypeType::LOW_COV)) lowCov_ += kv.second;
-            if (kv.first & static_cast<int>(HaplotypeType::OFFTARGET)) margOfftarget_ += kv.second;
-        }
+        reconstructedHaplotypes_ = std::move(reported);
+        filteredHaplotypes_ = std::move(counted);
     }
-    /// The report juliet writes with dump(2) (src/AminoAcidCaller.cpp:590-619).
+    /// The report juliet writes with dump(2); key names are the report format (src/AminoAcidCaller.cpp:590-619).
     JSON::Json JSON() const
     {
-        using JSON::Json;
-        Json root;
-        std::vector<Json> genes;
-        for (const auto& v : variantGenes_) {
-            Json j = v.ToJson();
-            if (j.find("variant_positions") != j.cend()) genes.push_back(j);
+        std::vector<JSON::Json> genes, haplotypes;
+        for (const VariantGene& gene : variantGenes_) {
+            JSON::Json entry = gene.ToJson();
+            if (entry.find("variant_positions") != entry.cend()) genes.push_back(std::move(entry));
         }
-        root["genes"] = genes;
-        std::vector<Json> haplotypes;
-        for (const auto& h : reconstructedHaplotypes_) haplotypes.push_back(h.ToJson());
-        root["haplotypes"] = haplotypes;
-        Json counts;
-        counts["healthy_reported"] = genCounts_;
-        counts["healthy_low_coverage"] = lowCov_;
-        counts["all_damaged"] = margOfftarget_;
-        counts["marginal_with_gaps"] = margWithGap_;
-        counts["marginal_with_heteroduplexes"] = margWithHetero_;
-        counts["marginal_partial_reads"] = margPartial_;
-        root["haplotype_read_counts"] = counts;
-        return root;
+        std::transform(reconstructedHaplotypes_.begin(), reconstructedHaplotypes_.end(), std::back_inserter(haplotypes),
+                       [](const Haplotype& h) { return h.ToJson(); });
+        return Msq::Obj({{"genes", genes},
+                         {"haplotypes", haplotypes},
+                         {"haplotype_read_counts",
+                          Msq::Obj({{"healthy_reported", genCounts_}, {"healthy_low_coverage", lowCov_}, {"all_damaged", margOfftarget_},
+                                    {"marginal_with_gaps", margWithGap_}, {"marginal_with_heteroduplexes", margWithHetero_},
+                                    {"marginal_partial_reads", margPartial_}})}});
     }
     const std::vector<Haplotype>& ReconstructedHaplotypes() const { return reconstructedHaplotypes_; }
     const std::vector<Haplotype>& FilteredHaplotypes() const { return filteredHaplotypes_; }
@@ -1035,41 +1076,48 @@ public:
 private:
     static constexpr float alpha = 0.01;  // AminoAcidCaller.h:108: a float, compared against doubles
 
-    std::string FindDRMs(const std::string& geneName, const std::vector<TargetGene>& genes, const DMutation curDRM) const
-    {  // src/AminoAcidCaller.cpp:105-124
-        std::string drmSummary;
-        for (const auto& gene : genes) {
-            if (geneName == gene.name) {
-                for (const auto& drms : gene.drms)
-                    if (std::find(drms.positions.cbegin(), drms.positions.cend(), curDRM) != drms.positions.cend()) {
-                        if (!drmSummary.empty()) drmSummary += " + ";
-                        drmSummary += drms.name;
-                    }
-                break;
-            }
-        }
-        return drmSummary;
+    /// Reorder `items` by a permutation that `sorter` establishes on the index vector 0 .. n-1.
+    template <typename T, typename Sorter>
+    static void OrderAs(std::vector<T>& items, Sorter sorter)
+    {
+        std::vector<size_t> order(items.size());
+        std::iota(order.begin(), order.end(), size_t(0));
+        sorter(order);
+        std::vector<T> out;
+        out.reserve(items.size());
+        for (const size_t i : order) out.push_back(std::move(items[i]));
+        items = std::move(out);
     }
-    bool MeasurePerformance(const TargetGene& tg, const std::string& codon, const bool& variableSite, const int& aaPos,
-                            const double& p, PerformanceMetrics* pm)
-    {  // src/AminoAcidCaller.cpp:341-378
-        const char aminoacid = AminoAcidTable::At(codon);
-        bool predictor = false;
-        for (const auto& minor : tg.minors)
-            if (aaPos == minor.position && aminoacid == minor.aminoacid[0] && codon == minor.codon) {
-                predictor = true;
-                break;
-            }
-        if (variableSite) {
-            if (predictor) {
-                if (p < alpha) ++pm->TruePositives; else ++pm->FalseNegative;
-            } else {
-                if (p < alpha) ++pm->FalsePositives; else ++pm->TrueNegative;
-            }
-        } else if (predictor) {
-            if (p < alpha) ++pm->TruePositives; else ++pm->FalseNegative;
+    /// " + "-joined names of the drugs of the first gene called geneName whose mutation list holds `mutation`
+    /// ('*' = any amino acid); the lookup of src/AminoAcidCaller.cpp:105-124.
+    static std::string FindDRMs(const std::string& geneName, const std::vector<TargetGene>& genes, const DMutation& mutation)
+    {
+        const auto gene = std::find_if(genes.begin(), genes.end(), [&](const TargetGene& g) { return g.name == geneName; });
+        std::string summary;
+        if (gene == genes.end()) return summary;
+        for (const DRM& drug : gene->drms) {
+            if (std::find(drug.positions.begin(), drug.positions.end(), mutation) == drug.positions.end()) continue;
+            if (!summary.empty()) summary += " + ";
+            summary += drug.name;
         }
-        return predictor;
+        return summary;
+    }
+    /// Is (aaPos, codon) one of the gene's expected minors?  Counts the call into the confusion matrix on the way:
+    /// a cell counts when the site is variable or the codon is expected; expected + significant is a true positive,
+    /// expected + not significant a false negative, and likewise false positive / true negative for the unexpected
+    /// (src/AminoAcidCaller.cpp:341-378).
+    static bool MeasurePerformance(const TargetGene& gene, int codonIndex, bool variableSite, int aaPos, double p, PerformanceMetrics* pm)
+    {
+        const std::string codon = Msq::CodonString(codonIndex);
+        const char aminoAcid = AminoAcidTable::FromCodonIndex(codonIndex);
+        const bool expected = std::any_of(gene.minors.begin(), gene.minors.end(), [&](const ExpectedMinor& m) {
+            return m.position == aaPos && m.aminoacid[0] == aminoAcid && m.codon == codon;
+        });
+        if (variableSite || expected) {
+            double* const cell[2][2] = {{&pm->TrueNegative, &pm->FalsePositives}, {&pm->FalseNegative, &pm->TruePositives}};
+            ++*cell[expected][p < alpha];
+        }
+        return expected;
     }
 
     void CallVariants()  // src/AminoAcidCaller.cpp:397-577: the cell arithmetic runs on the GPU, the store policy here
@@ -1138,29 +1186,27 @@ private:
                     const int count = (int)codonCounts[(size_t)pos.win_pos * 64 + c];
                     const double frequency = 1.0 * count / coverage;  // :491
                     const bool variableSite = frequency < 0.8;        // :492
-                    const bool predictorSite = MeasurePerformance(gene, codon, variableSite, aaPos, p, pm_.get());
-                    auto StoreVariant = [&]() {  // :499-516
-                        if (debug_ || frequency * 100 >= minimalPerc_) {
-                            const char curAA = AminoAcidTable::FromCodonIndex(c);
-                            VariantGene::VariantPosition::VariantCodon vc;
-                            vc.codon = codon;
-                            vc.frequency = frequency;
-                            vc.pValue = p;
-                            vc.knownDRM = FindDRMs(gene.name, genes, DMutation(cur->refAminoAcid, aaPos, curAA));
-                            cur->aminoAcidToCodons[curAA].push_back(vc);
-                        }
-                    };
-                    if (debug_) {  // :519-539
-                        StoreVariant();
-                    } else if (p < alpha) {
-                        if (drmOnly_) {
-                            if (!FindDRMs(gene.name, genes, DMutation(cur->refAminoAcid, aaPos, AminoAcidTable::FromCodonIndex(c))).empty())
-                                StoreVariant();
-                        } else {
-                            if (predictorSite) StoreVariant();
-                            else if (hasExpectedMinors && variableSite) StoreVariant();
-                            else if (!hasExpectedMinors) StoreVariant();
-                        }
+                    const bool expectedMinor = MeasurePerformance(gene, c, variableSite, aaPos, p, pm_.get());
+                    // Which cells are kept (the policy of src/AminoAcidCaller.cpp:499-539): with --debug everything;
+                    // otherwise only significant cells (p < alpha, alpha a float), and of those -- with --drm-only the
+                    // known resistance mutations; with expected minors configured the expected ones and everything at
+                    // variable sites; without them all.  A kept cell is stored when --debug or its frequency reaches
+                    // --min-perc.
+                    const char curAA = AminoAcidTable::FromCodonIndex(c);
+                    bool keep = debug_;
+                    if (!keep && p < alpha) {
+                        if (drmOnly_)
+                            keep = !FindDRMs(gene.name, genes, DMutation(cur->refAminoAcid, aaPos, curAA)).empty();
+                        else
+                            keep = expectedMinor || !hasExpectedMinors || variableSite;
+                    }
+                    if (keep && (debug_ || frequency * 100 >= minimalPerc_)) {
+                        VariantGene::VariantPosition::VariantCodon vc;
+                        vc.codon = codon;
+                        vc.frequency = frequency;
+                        vc.pValue = p;
+                        vc.knownDRM = FindDRMs(gene.name, genes, DMutation(cur->refAminoAcid, aaPos, curAA));
+                        cur->aminoAcidToCodons[curAA].push_back(vc);
                     }
                 }
                 if (!cur->aminoAcidToCodons.empty()) {  // :544-566

@@ -445,3 +445,19 @@ def fisher_batch(ctx, a, b, c, d):
     p = np.zeros(len(a), dtype=np.float64)
     abi.check(abi.lib().msq_fisher_batch(ctx.h, len(a), abi.ptr(a), abi.ptr(b), abi.ptr(c), abi.ptr(d), abi.ptr(p)))
     return p
+
+
+def phase_cluster(ctx, keys, n_reads, K, with_rows=True):
+    """msq_phase_cluster on a device tensor of key rows [n_reads * K] (int16 view of u16) ->
+    (cluster_of [n_reads], first_read [C], count [C], rep_rows [C, K] or None), numpy."""
+    dev = torch.device("cuda", ctx.device)
+    cluster_of = torch.zeros(max(n_reads, 1), dtype=torch.int32, device=dev)
+    first = torch.zeros(max(n_reads, 1), dtype=torch.int32, device=dev)
+    count = torch.zeros(max(n_reads, 1), dtype=torch.int32, device=dev)
+    rep = torch.zeros(max(n_reads * K, 1), dtype=torch.int16, device=dev) if with_rows else None
+    n = C.c_uint64(0)
+    abi.check(abi.lib().msq_phase_cluster(ctx.h, keys.data_ptr(), n_reads, K, cluster_of.data_ptr(), first.data_ptr(), count.data_ptr(),
+                                          rep.data_ptr() if with_rows else None, n_reads, C.byref(n)))
+    c = int(n.value)
+    return (cluster_of.cpu().numpy()[:n_reads].astype(np.int64), first.cpu().numpy()[:c].astype(np.int64), count.cpu().numpy()[:c].astype(np.int64),
+            rep.cpu().numpy().view(np.uint16)[:c * K].reshape(c, K) if with_rows else None)
