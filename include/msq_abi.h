@@ -48,6 +48,7 @@ int msq_dev_free(msq_ctx* ctx, void* d_ptr);
 int msq_dev_memset(msq_ctx* ctx, void* d_ptr, int value, size_t bytes);           /* async on the stream */
 int msq_memcpy_h2d(msq_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);   /* async on the stream */
 int msq_memcpy_d2h(msq_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);   /* synchronises */
+int msq_memcpy_d2d(msq_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);   /* async on the stream */
 
 /* ------------------------------------------------------------------------------------- packed read format
  * Replaces the in-memory type of the path, std::vector<ArrayBase> per ArrayRead
@@ -236,7 +237,7 @@ int msq_pileup_partition(msq_ctx* ctx, const msq_partition* p, const msq_qv_thre
 /* msq_pileup for callers that must not allocate (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  No counterpart in the reference.  Same result as msq_pileup(..., MSQ_PILEUP_STREAM), added into
  * the caller's matrices, but the one buffer the pileup needs beyond its inputs and outputs -- the per-workgroup
- * partial counts -- lives in a device array built into the library (20 MiB per GPU, held until the process ends)
+ * partial counts -- lives in a device array built into the library (32 MiB per GPU, held until the process ends)
  * instead of the context's scratch, and the call makes no hipMalloc / hipFree.  Limits: W <= 4096 columns (one
  * column slab), GPUs of up to 256 CUs, reads without MSQ_READS_HAS_EXOTIC; anything beyond is refused with
  * MSQ_ERR_ARG.  All calls on one GPU share that array: calls that overlap on one GPU (two contexts or two streams)
@@ -333,6 +334,7 @@ int msq_timing_read_path(msq_ctx* ctx, float* ms_out, int32_t capacity, int32_t*
 int msq_comm_unique_id(uint8_t* id_out /* [MSQ_COMM_ID_BYTES] */);   /* host */
 int msq_comm_create(msq_ctx* ctx, int rank, int world, const uint8_t* id);  /* collective over the ranks; synchronises */
 int msq_comm_destroy(msq_ctx* ctx);
+int msq_comm_active(const msq_ctx* ctx); /* 1 when the context has a communicator (even of one rank) */
 int msq_comm_rank(const msq_ctx* ctx);   /* 0 without a communicator */
 int msq_comm_world(const msq_ctx* ctx);  /* 1 without a communicator */
 /* Contiguous read range of a rank, [rank * N / world, (rank + 1) * N / world).  Host. */

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "msq_dev_memset": (C.c_int, [_P, _P, C.c_int, C.c_size_t]),
     "msq_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "msq_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "msq_memcpy_d2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "msq_qv_thresholds_from_env": (C.c_int, [C.POINTER(QvThresholds)]),
     "msq_pack_reads": (C.c_int, [C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_P)]),
     "msq_packed_host_view": (C.POINTER(PackedReads), [_P]),
@@ -124,6 +125,7 @@ _SIGNATURES = {
     "msq_comm_unique_id": (C.c_int, [_P]),
     "msq_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "msq_comm_destroy": (C.c_int, [_P]),
+    "msq_comm_active": (C.c_int, [_P]),
     "msq_comm_rank": (C.c_int, [_P]),
     "msq_comm_world": (C.c_int, [_P]),
     "msq_comm_shard": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

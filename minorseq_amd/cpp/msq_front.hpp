@@ -69,6 +69,16 @@ inline msq_ctx* Context()
     }();
     return ctx;
 }
+/// One rank of a read-sharded run (one process per GPU): binds the library's RCCL communicator to this process's
+/// context.  `id` = the MSQ_COMM_ID_BYTES that msq_comm_unique_id() produced on rank 0, handed to every rank by the
+/// caller (MPI, a file, ...).  From then on every MSAByRow / AminoAcidCaller takes the reads it is given as the WHOLE
+/// sample, piles up only its own share [rank * N / world, (rank + 1) * N / world) and merges window bounds and count
+/// matrices over the ranks (msq_comm_allreduce_*), so that every rank ends up with the same matrices, calls and
+/// haplotypes as a single-GPU run.  Call it before the first MSA is built.
+inline void SetCommunicator(int rank, int world, const uint8_t* id) { Check(msq_comm_create(Context(), rank, world, id)); }
+inline int CommRank() { return msq_comm_rank(Context()); }
+inline int CommWorld() { return msq_comm_world(Context()); }
+inline bool CommActive() { return msq_comm_active(Context()) != 0; }
 template <typename T>
 class DeviceBuffer
 {
@@ -227,35 +237,39 @@ public:
         const QvThresholds qv;
         numReads_ = source.names.size();
         names_ = source.names;
+        TakeShare(insertions);
         struct Relay  // the callback crosses a C boundary: keep the first exception and rethrow it afterwards
         {
             const ReadSource* source;
+            uint64_t first;  // this rank's first read
             std::mutex mutex;
             std::exception_ptr error;
             static void Fill(void* user, uint64_t read, msq_array_base* dst)
             {
                 Relay* self = static_cast<Relay*>(user);
                 try {
-                    self->source->fill(read, reinterpret_cast<ArrayBase*>(dst));
+                    self->source->fill(self->first + read, reinterpret_cast<ArrayBase*>(dst));
                 } catch (...) {
                     std::lock_guard<std::mutex> lock(self->mutex);
                     if (!self->error) self->error = std::current_exception();
                 }
             }
-        } relay{&source, {}, nullptr};
+        } relay{&source, shareFirst_, {}, nullptr};
         msq_packed_dev* dev = nullptr;
         const uint32_t packFlags = insertions == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
         // the thresholds are fixed for the life of the MSA (MSA.h:82): they are applied while packing -- failing match
         // bases become the 'N' AddRead writes (src/MSA.cpp:165-166) and no QV plane ever reaches HBM
         const msq_qv_thresholds thr{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
-        const int rc = msq_pack_reads_device_fill_baked(Msq::Context(), numReads_, source.referenceStart.data(), source.referenceEnd.data(),
-                                                        source.numBases.data(), &Relay::Fill, &relay, packFlags, 0, 0, &thr, &dev);
+        const int rc = msq_pack_reads_device_fill_baked(Msq::Context(), shareCount_, source.referenceStart.data() + shareFirst_,
+                                                        source.referenceEnd.data() + shareFirst_, source.numBases.data() + shareFirst_,
+                                                        &Relay::Fill, &relay, packFlags, 0, 0, &thr, &dev);
         if (relay.error) {
             if (dev) msq_packed_dev_free(Msq::Context(), dev);
             std::rethrow_exception(relay.error);
         }
         Msq::Check(rc);
-        Finish(dev, numReads_ == 0, qv, insertions, [&source](uint64_t read, uint32_t first, uint32_t len) {
+        Finish(dev, numReads_ == 0, qv, insertions, [&source, this](uint64_t read, uint32_t first, uint32_t len) {
+            read += shareFirst_;
             std::vector<ArrayBase> bases((size_t)source.numBases[read], ArrayBase('P', '*'));
             source.fill(read, bases.data());
             std::string s(len, 'A');
@@ -292,7 +306,7 @@ public:
     }
     const std::vector<uint32_t>& NucleotideCounts() const { return nuc_; }  // [W][6]
     const std::vector<uint32_t>& CodonCounts() const { return codon_; }     // [W][64]
-    const uint32_t* DeviceCodonCounts() const { return dCodon_ ? dCodon_->get() : nullptr; }
+    const uint32_t* DeviceCodonCounts() const { return dCounts_ ? dCounts_->get() + (size_t)width_ * 6 : nullptr; }
     size_t NumReads() const { return numReads_; }
     /// Names of the reads, in row order (MSARow::Read->Name(), src/MSA.cpp:100-104).
     const std::vector<std::string>& ReadNames() const { return names_; }
@@ -327,7 +341,7 @@ public:
         const size_t K = pos.size();
         msq_ctx* ctx = Msq::Context();
         Msq::DeviceBuffer<uint16_t> dKeys(numReads_ * K);
-        if (K) GatherKeys(pos, dKeys.get());
+        if (K) GatherKeys(pos, dKeys.get());  // every read's keys, on every rank
         Msq::DeviceBuffer<uint32_t> dGroup(numReads_), dFirst(numReads_), dSize(numReads_);
         Msq::DeviceBuffer<uint16_t> dRows(numReads_ * K);
         uint64_t n = 0;
@@ -369,11 +383,41 @@ public:
     }
 
 private:
+    // This rank's share of a sample of numReads_ reads.  The insertion histogram is per read, not additive
+    // per column: an MSA that collects it keeps every read on every rank.
+    void TakeShare(InsertionMode insertions)
+    {
+        shareFirst_ = 0;
+        shareCount_ = numReads_;
+        sharded_ = Msq::CommActive() && insertions == InsertionMode::None;
+        if (sharded_) {
+            uint64_t first = 0, count = 0;
+            Msq::Check(msq_comm_shard(numReads_, Msq::CommRank(), Msq::CommWorld(), &first, &count));
+            shareFirst_ = (size_t)first;
+            shareCount_ = (size_t)count;
+        }
+    }
+    // keys of all numReads_ reads into dKeys [numReads_][K]: this rank gathers its own reads' keys; on a sharded sample
+    // the shares (padded to the largest) are all-gathered and laid out in read order
     void GatherKeys(const std::vector<int32_t>& pos, uint16_t* dKeys) const
     {
-        Msq::Check(msq_phase_codons(Msq::Context(), msq_packed_dev_view(dev_.get()), &thr_, beginPos_ - 1, width_, (int32_t)pos.size(),
-                                    pos.data(), dKeys));
-        Msq::Check(msq_pileup_check(Msq::Context()));
+        msq_ctx* ctx = Msq::Context();
+        const size_t K = pos.size();
+        const bool sharded = sharded_;
+        const int world = sharded ? Msq::CommWorld() : 1;
+        const size_t most = sharded ? (numReads_ + world - 1) / world : numReads_;  // the largest share
+        Msq::DeviceBuffer<uint16_t> dMine(sharded ? most * K : 0), dAll(sharded ? most * K * world : 0);
+        uint16_t* const mine = sharded ? dMine.get() : dKeys;
+        Msq::Check(msq_phase_codons(ctx, msq_packed_dev_view(dev_.get()), &thr_, beginPos_ - 1, width_, (int32_t)K, pos.data(), mine));
+        Msq::Check(msq_pileup_check(ctx));
+        if (!sharded) return;
+        Msq::Check(msq_comm_allgather(ctx, dMine.get(), dAll.get(), most * K * sizeof(uint16_t)));
+        for (int r = 0; r < world; ++r) {
+            uint64_t first = 0, count = 0;
+            Msq::Check(msq_comm_shard(numReads_, r, world, &first, &count));
+            Msq::Check(msq_memcpy_d2d(ctx, dKeys + first * K, dAll.get() + (size_t)r * most * K, count * K * sizeof(uint16_t)));
+        }
+        Msq::Check(msq_ctx_sync(ctx));
     }
     // The insertion histogram: count the recorded insertions per column on the GPU, pick the columns
     // that matter, fetch their (column, string) records and add them up.
@@ -425,6 +469,7 @@ private:
         const QvThresholds qv;  // member qvThresholds_ of the reference: read from the environment per MSA (MSA.h:82)
         numReads_ = reads.size();
         for (const auto* r : reads) names_.push_back(r->Name());
+        TakeShare(insertionMode);
         // the reads' ArrayBase arrays go to the GPU as they are (8-byte records); msq_pack_reads_device copies them
         // through pinned staging and translates / packs them on the device
         static_assert(sizeof(ArrayBase) == sizeof(msq_array_base) && offsetof(ArrayBase, Cigar) == offsetof(msq_array_base, cigar) &&
@@ -437,11 +482,12 @@ private:
         std::vector<int32_t> rs, re;
         std::vector<const msq_array_base*> ptr;
         std::vector<int64_t> len;
-        rs.reserve(reads.size());
-        re.reserve(reads.size());
-        ptr.reserve(reads.size());
-        len.reserve(reads.size());
-        for (const auto* r : reads) {
+        rs.reserve(shareCount_);
+        re.reserve(shareCount_);
+        ptr.reserve(shareCount_);
+        len.reserve(shareCount_);
+        for (size_t k = shareFirst_; k < shareFirst_ + shareCount_; ++k) {
+            const ArrayRead* r = reads[k];
             rs.push_back(r->ReferenceStart());
             re.push_back(r->ReferenceEnd());
             ptr.push_back(reinterpret_cast<const msq_array_base*>(r->Bases().data()));
@@ -453,10 +499,10 @@ private:
         // the insertion scan needs the genomic order inside each group (plain layout); the pileup takes both
         const uint32_t packFlags = insertionMode == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
         const msq_qv_thresholds thr{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};  // applied while packing, as above
-        Msq::Check(msq_pack_reads_device_baked(ctx, reads.size(), rs.data(), re.data(), ptr.data(), len.data(), packFlags, 0, 0, &thr, &dev));
-        Finish(dev, reads.empty(), qv, insertionMode, [&reads](uint64_t read, uint32_t first, uint32_t len) {
+        Msq::Check(msq_pack_reads_device_baked(ctx, shareCount_, rs.data(), re.data(), ptr.data(), len.data(), packFlags, 0, 0, &thr, &dev));
+        Finish(dev, reads.empty(), qv, insertionMode, [&reads, this](uint64_t read, uint32_t first, uint32_t len) {
             std::string s(len, 'A');
-            for (uint32_t i = 0; i < len; ++i) s[i] = reads[read]->Bases()[first + i].Nucleotide;
+            for (uint32_t i = 0; i < len; ++i) s[i] = reads[shareFirst_ + read]->Bases()[first + i].Nucleotide;
             return s;
         });
     }
@@ -470,17 +516,26 @@ private:
         dev_.reset(dev, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // kept for PhaseKeys
         thr_ = msq_qv_thresholds{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
         {
-            int32_t b0 = 0, e0 = 0;
-            Msq::Check(msq_window_bounds(ctx, msq_packed_dev_view(dev), &b0, &e0));
+            // UpdateBoundaries over this rank's reads, left in HBM as {-begin, end}; one MAX over the ranks makes it the
+            // sample's window (a no-op without a communicator); then it comes to the host, which sizes the matrices
+            Msq::DeviceBuffer<int32_t> dBounds(2);
+            Msq::Check(msq_window_bounds_device(ctx, msq_packed_dev_view(dev), dBounds.get()));
+            if (sharded_) Msq::Check(msq_comm_allreduce_bounds(ctx, dBounds.get()));
+            const std::vector<int32_t> bounds = dBounds.ToHost();
+            const int32_t b0 = -bounds[0], e0 = bounds[1];
             width_ = reads.empty() ? 0 : e0 - b0;
             beginPos_ = b0;
             endPos_ = e0;
-            dNuc_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 6));
-            dCodon_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 64));
-            Msq::Check(msq_pileup(ctx, msq_packed_dev_view(dev), &thr_, b0, width_, dNuc_->get(), dCodon_->get(), MSQ_PILEUP_AUTO));
+            // [W][6] nucleotide counts, then [W][64] codon counts, in one buffer: one u32 SUM over the ranks
+            dCounts_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 70));
+            uint32_t* const dNuc = dCounts_->get();
+            uint32_t* const dCodon = dNuc + (size_t)width_ * 6;
+            Msq::Check(msq_pileup(ctx, msq_packed_dev_view(dev), &thr_, b0, width_, dNuc, dCodon, MSQ_PILEUP_AUTO));
+            if (sharded_) Msq::Check(msq_comm_allreduce_counts(ctx, dNuc, (size_t)width_ * 70));
             Msq::Check(msq_pileup_check(ctx));  // "Unexpected base ..." -> std::runtime_error
-            nuc_ = dNuc_->ToHost();
-            codon_ = dCodon_->ToHost();
+            const std::vector<uint32_t> counts = dCounts_->ToHost();
+            nuc_.assign(counts.begin(), counts.begin() + (size_t)width_ * 6);
+            codon_.assign(counts.begin() + (size_t)width_ * 6, counts.end());
             if (insertionMode != InsertionMode::None) CollectInsertions(ctx, msq_packed_dev_view(dev), b0, insertionMode, basesOf);
         }
         if (!reads.empty()) {  // ++beginPos_, ++endPos_ (src/MSA.cpp:107-108)
@@ -497,7 +552,9 @@ private:
     int width_ = 0;
     size_t numReads_ = 0;
     std::vector<uint32_t> nuc_, codon_;
-    std::shared_ptr<Msq::DeviceBuffer<uint32_t>> dNuc_, dCodon_;
+    std::shared_ptr<Msq::DeviceBuffer<uint32_t>> dCounts_;
+    size_t shareFirst_ = 0, shareCount_ = 0;  // the reads this rank packed and piled up (all of them on one GPU)
+    bool sharded_ = false;                    // a communicator is bound and this MSA took its share
     std::shared_ptr<msq_packed_dev> dev_;  // the packed reads stay in HBM for the phasing pass
     msq_qv_thresholds thr_{-1, -1, -1, -1};
     std::vector<std::string> names_;

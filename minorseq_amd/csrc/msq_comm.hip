@@ -117,6 +117,7 @@ extern "C" int msq_comm_destroy(msq_ctx* ctx)
     return MSQ_OK;
 }
 
+extern "C" int msq_comm_active(const msq_ctx* ctx) { return ctx && ctx->comm ? 1 : 0; }
 extern "C" int msq_comm_rank(const msq_ctx* ctx) { return ctx && ctx->comm ? ctx->comm->rank : 0; }
 extern "C" int msq_comm_world(const msq_ctx* ctx) { return ctx && ctx->comm ? ctx->comm->world : 1; }
 

@@ -142,6 +142,13 @@ extern "C" int msq_memcpy_d2h(msq_ctx* ctx, void* h_dst, const void* d_src, size
     return MSQ_OK;
 }
 
+extern "C" int msq_memcpy_d2d(msq_ctx* ctx, void* d_dst, const void* d_src, size_t bytes)
+{
+    if (!ctx || ((!d_dst || !d_src) && bytes)) return msq_fail(MSQ_ERR_ARG, "msq_memcpy_d2d: NULL argument");
+    if (bytes) MSQ_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return MSQ_OK;
+}
+
 static void timing_release(msq_ctx* ctx)
 {
     for (auto e : ctx->ev_begin) (void)hipEventDestroy(e);

@@ -36,6 +36,9 @@
 // MSQ_EXP: compile-time timing experiments only (make EXTRA=-DMSQ_EXP=n); any non-zero value gives WRONG counts.
 // bit 0 skip the LDS ORs of phase 1, bit 1 skip phase 2 + drain, bit 2 skip the squeeze, bit 3 skip the drain,
 // bit 4 skip zero_rows, bit 5 skip the counter transposition of the flush.  The shipped library is always built with 0.
+#ifndef MSQ_NO_ALT  // experiment builds: every deviation from the guide pays a global atomic, as before the alt haplotype
+#define MSQ_NO_ALT 0
+#endif
 #ifndef MSQ_W12
 #define MSQ_W12 0
 #endif
@@ -79,9 +82,10 @@ struct StreamArgs {
     int32_t G;           // 32-column words of the slab (<= 128)
     int32_t RD;          // words per LDS row: a margin word, the slab's G words, two margin words, a zero pad word
     uint32_t normalized; // MSQ_READS_NORMALIZED: consuming bases lead every group, no compaction needed
+    uint32_t alt_on;     // the launch has LDS for the alt-haplotype counters (one u32 per slab column)
     uint32_t* nuc;
     uint32_t* codon;
-    uint32_t* partials;  // [gridDim.x][NC + 1][G*32]
+    uint32_t* partials;  // [gridDim.x][NC + 4][G*32]
     uint32_t* err;
     // the phasing gather (pileup_kernel<.., PHASE = true>): window positions whose codon starts in this slab
     const int32_t* ph_pos;  // [ph_n] CodonAt arguments (window columns)
@@ -236,33 +240,89 @@ __device__ __forceinline__ uint32_t codon_cols_of(int cg, int W)  // cg: word of
     return lo <= hi ? (0xffffffffu >> (31 - hi)) & (0xffffffffu << lo) : 0u;
 }
 
-// Per-column majority base over every wave's first batch -> the workgroup's guide words gl[G + 1][4] (valid,
-// code bit 0, code bit 1, 0).  Runs once per workgroup; kept out of line so its registers do not add to the
-// streaming loop's budget.  Rows are [8][RD][4 planes V X B0 B1], WV dwords per wave.
-__device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl, int NWV, int WV, int RD, int G, int tid, int T)
+// bit-sliced compare: a > b, per column
+template <int L>
+__device__ __forceinline__ uint32_t sliced_gt(const uint32_t (&a)[L], const uint32_t (&b)[L])
+{
+    uint32_t gt = 0, eq = ~0u;
+#pragma unroll
+    for (int l = L - 1; l >= 0; --l) {
+        gt |= eq & a[l] & ~b[l];
+        eq &= ~(a[l] ^ b[l]);
+    }
+    return gt;
+}
+
+// The workgroup's guide, learnt from every wave's first batch (64 .. 96 reads): per column the most common base
+// -> gl[G + 3][4] = (valid, code bit 0, code bit 1, 0) -- and the runner-up, if any read carries a second base (a
+// minor variant at >= ~3 % is caught by most workgroups; a sequencing error caught instead costs nothing, it is an
+// alt that never matches again) -> the ALT haplotype gl2[G + 3][4] = (valid, bit 0, bit 1, has-a-runner-up): the
+// runner-up's base where there is one, the guide's base elsewhere.  Cells that match the guide
+// are counted in registers; cells that deviate from it but match the alt haplotype are counted in LDS (the drain);
+// only what matches neither costs a global atomic.  Runs once per workgroup; kept out of line so its registers do
+// not add to the streaming loop's budget.  Rows are [8][RD][4 planes V X B0 B1], WV dwords per wave.
+__device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl, uint32_t* gl2, int NWV, int WV, int RD, int G, int tid, int T)
 {
     const int ROWB = RD * 4;
     for (int cg = tid; cg <= G; cg += T) {  // word G = the first word behind the slab: codons reach into it
-        uint32_t cv[8], c0[8], c1[8];  // 8 levels: up to 255 rows (12 waves x 8 = 96)
+        uint32_t cnt[4][8];  // per base; 8 levels: up to 255 rows (12 waves x 8 = 96)
 #pragma unroll
-        for (int l = 0; l < 8; ++l) cv[l] = c0[l] = c1[l] = 0;
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) cnt[b][l] = 0;
         for (int wv = 0; wv < NWV; ++wv) {
-            uint32_t xv[kRows], x0[kRows], x1[kRows];
+            uint32_t x[4][kRows];
 #pragma unroll
             for (int i = 0; i < kRows; ++i) {
                 const uint4 w = *reinterpret_cast<const uint4*>(lds + wv * WV + i * ROWB + (cg + 1) * 4);
-                xv[i] = w.x;
-                x0[i] = w.z & w.x;  // the X cells reuse B0 for 'N': only valid bases vote
-                x1[i] = w.w;
+                x[0][i] = w.x & ~w.z & ~w.w;  // only valid bases vote (the X cells reuse B0 for 'N')
+                x[1][i] = w.x & w.z & ~w.w;
+                x[2][i] = w.x & ~w.z & w.w;
+                x[3][i] = w.x & w.z & w.w;
             }
-            counter_add8(cv, xv);
-            counter_add8(c0, x0);
-            counter_add8(c1, x1);
-        }
-        uint32_t any = 0;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) any |= cv[l];
-        *reinterpret_cast<uint4*>(gl + cg * 4) = make_uint4(any, any & sliced_twice_gt(c0, cv), any & sliced_twice_gt(c1, cv), 0u);
+            for (int b = 0; b < 4; ++b) counter_add8(cnt[b], x[b]);
+        }
+        uint32_t any = 0, seen[4];  // seen: at least one read carries the base
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            seen[b] = 0;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) seen[b] |= cnt[b][l];
+            any |= seen[b];
+        }
+        // beats(i, j): base i ranks before base j -- the larger count, the smaller index among equals
+        uint32_t beats[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 4; ++j) {
+                const uint32_t later_wins = sliced_gt(cnt[j], cnt[i]);
+                beats[j][i] = later_wins;
+                beats[i][j] = ~later_wins;
+            }
+        uint32_t best[4], second[4], has_alt = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t m = any;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j != i) m &= beats[i][j];
+            best[i] = m;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t m = any & ~best[i] & seen[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j != i) m &= best[j] | beats[i][j];
+            second[i] = m;
+            has_alt |= m;
+        }
+        const uint32_t g0 = best[1] | best[3], g1 = best[2] | best[3];
+        const uint32_t a0 = second[1] | second[3], a1 = second[2] | second[3];
+        *reinterpret_cast<uint4*>(gl + cg * 4) = make_uint4(any, g0, g1, 0u);
+        *reinterpret_cast<uint4*>(gl2 + cg * 4) = make_uint4(any, (has_alt & a0) | (~has_alt & g0), (has_alt & a1) | (~has_alt & g1), has_alt);
     }
 }
 
@@ -509,6 +569,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     uint16_t* const queue = reinterpret_cast<uint16_t*>(wrow + kRows * ROWB);
     uint32_t* const draw_ctr = lds + NWV * WV;                // the workgroup's batch counter (BatchDraw)
     uint32_t* const gl = draw_ctr + 4;                        // the workgroup's guide words [G + 3][4]
+    uint32_t* const gl2 = gl + 4 * (G + 3);                   // the alt haplotype [G + 3][4] (learn_guide_words)
+    uint32_t* const altc = gl2 + 4 * (G + 3);                 // [G * 32] per column: alt nucleotide count | alt codon count << 16
+    const bool alt_on = !PHASE && a.alt_on != 0;
 
     // ---- phase-2 identity: in pass p this lane owns word cgp[p].  The last pass, when at most 32 words wide,
     // splits the batch's rows between the two halves of the wave (rows rbase .. rbase+3).
@@ -536,7 +599,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             gl[2 * i + 1] = (uint32_t)a.ph_idx[i];
         }
     } else {
-        for (int i = tid; i < 4 * (G + 3); i += T) gl[i] = 0;
+        for (int i = tid; i < 8 * (G + 3) + (alt_on ? G * 32 : 0); i += T) gl[i] = 0;  // guide, alt haplotype, alt counters
     }
     __syncthreads();
     BatchDraw bd;
@@ -740,16 +803,34 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             const uint32_t cv = lo.x & funnel(lo.x, hi.x, 1) & funnel(lo.x, hi.x, 2) & cc;
             const uint32_t nd = lo.x & ~m_lo, cd = cv & ~cm, nn = COUNT_N ? 0u : (lo.y & lo.z);
             const int cbase = (wbase + cg) * 32;
+            // deviations that match the workgroup's alt haplotype -- a minor variant carried by a share of the reads --
+            // are counted in LDS (returnless ds_add, ~1/100 of a global atomic's cost; the sum goes out with the
+            // workgroup's partial); only what matches neither the guide nor the alt haplotype pays a global atomic
+            uint32_t nd_alt = 0, cd_alt = 0;
+            if (alt_on) {  // wave-uniform
+                const uint4 al = *reinterpret_cast<const uint4*>(gl2 + cg * 4), ah = *reinterpret_cast<const uint4*>(gl2 + cg * 4 + 4);
+                const uint32_t am_lo = lo.x & al.x & ~((lo.z ^ al.y) | (lo.w ^ al.z));
+                const uint32_t am_hi = hi.x & ah.x & ~((hi.z ^ ah.y) | (hi.w ^ ah.z));
+                nd_alt = nd & am_lo;
+                cd_alt = cd & am_lo & funnel(am_lo, am_hi, 1) & funnel(am_lo, am_hi, 2);
+                uint32_t bits = nd_alt | cd_alt;
+                while (bits) {
+                    const int j = __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    __hip_atomic_fetch_add(&altc[cg * 32 + j], ((nd_alt >> j) & 1u) | (((cd_alt >> j) & 1u) << 16), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
             // two tight loops instead of one that carries all three cases: a deviating base (or, without an N
             // counter, an N) is one atomic on its nucleotide bin, a deviating codon one on its codon bin
-            uint32_t bits = nd | nn;  // disjoint: nd lies in V, nn in X
+            uint32_t bits = (nd & ~nd_alt) | nn;  // disjoint: nd lies in V, nn in X
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
                 const uint32_t code = ((nn >> j) & 1u) ? 5u : (((lo.z >> j) & 1u) | (((lo.w >> j) & 1u) << 1));
                 atomicAdd(&a.nuc[(uint32_t)(cbase + j) * 6u + code], 1u);
             }
-            bits = cd;
+            bits = cd & ~cd_alt;
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
@@ -791,7 +872,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     // ---- the workgroup's guide = per-column majority base over every wave's first batch
     auto learn_guide = [&]() {
         __syncthreads();  // every wave's first batch is in its rows
-        learn_guide_words(lds, gl, NWV, WV, RD, G, tid, T);
+        learn_guide_words(lds, gl, gl2, NWV, WV, RD, G, tid, T);
         __syncthreads();
     };
 
@@ -877,13 +958,21 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     __syncthreads();
     MSQ_TR();
     const int cols = G * 32;
-    uint32_t* const part = a.partials + (size_t)blockIdx.x * (NC + 1) * cols;
-    auto gbit = [&](int plane, int c) -> uint32_t { return (gl[(c >> 5) * 4 + plane] >> (c & 31)) & 1u; };
+    uint32_t* const part = a.partials + (size_t)blockIdx.x * (NC + 4) * cols;
+    // per column what the counters stand for: the guide's (plane set 0) and the alt haplotype's (plane set 1)
+    // nucleotide and codon bins; then the alt counts the drain collected in LDS
+    auto meta_of = [&](const uint32_t* g, int c) -> uint32_t {
+        auto bit = [&](int plane, int cc) -> uint32_t { return (g[(cc >> 5) * 4 + plane] >> (cc & 31)) & 1u; };
+        const uint32_t v0 = bit(0, c), v1 = bit(0, c + 1), v2 = bit(0, c + 2);
+        const uint32_t k0 = bit(1, c) | (bit(2, c) << 1), k1 = bit(1, c + 1) | (bit(2, c + 1) << 1), k2 = bit(1, c + 2) | (bit(2, c + 2) << 1);
+        return k0 | (v0 << 2) | (((k0 << 4) | (k1 << 2) | k2) << 8) | ((v0 & v1 & v2) << 14);
+    };
     for (int c = tid; c < cols; c += T) {
-        const uint32_t v0 = gbit(0, c), v1 = gbit(0, c + 1), v2 = gbit(0, c + 2);
-        const uint32_t k0 = gbit(1, c) | (gbit(2, c) << 1), k1 = gbit(1, c + 1) | (gbit(2, c + 1) << 1),
-                       k2 = gbit(1, c + 2) | (gbit(2, c + 2) << 1);
-        part[(size_t)NC * cols + c] = k0 | (v0 << 2) | (((k0 << 4) | (k1 << 2) | k2) << 8) | ((v0 & v1 & v2) << 14);
+        part[(size_t)NC * cols + c] = meta_of(gl, c);
+        const uint32_t ac = alt_on ? altc[c] : 0u;
+        part[(size_t)(NC + 1) * cols + c] = ac & 0xffffu;
+        part[(size_t)(NC + 2) * cols + c] = ac >> 16;
+        part[(size_t)(NC + 3) * cols + c] = meta_of(gl2, c);
     }
     // The kernels that carry QV planes through the loop sit at the register limit: they keep the plain flush (every
     // wave transposes its own counters and adds them into LDS accumulators); a run normally bakes the thresholds
@@ -979,37 +1068,47 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const uint32_t* __re
     if (c >= cols || col0 + c >= W) return;
     nuc += (size_t)col0 * 6;
     codon += (size_t)col0 * 64;
-    uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0, cod_sum = 0;
-    int cod_idx = -1;
+    uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0;
+    // codon counts: runs of workgroups that agree on the bin are added up before they cost an atomic (set 0 = the
+    // guide's codon, set 1 = the alt haplotype's)
+    uint32_t cod_sum[2] = {0, 0};
+    int cod_idx[2] = {-1, -1};
+    auto add_codon = [&](int set, uint32_t meta, uint32_t n) {
+        if (!n) return;
+        const int idx = (int)((meta >> 8) & 63u);
+        if (idx != cod_idx[set]) {
+            if (cod_sum[set]) atomicAdd(&codon[(size_t)c * 64 + cod_idx[set]], cod_sum[set]);
+            cod_idx[set] = idx;
+            cod_sum[set] = 0;
+        }
+        cod_sum[set] += n;
+    };
     // four workgroups' partials per trip, all their loads in flight together (the kernel is latency-bound)
     for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += 16) {
-        uint32_t meta[4], m[4], g[4], cm[4], n4[4];
+        uint32_t meta[4], m[4], g[4], cm[4], n4[4], am[4], acm[4], meta2[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int wg = min(wg0 + 4 * u, wg_hi - 1);  // clamped: a slot past the end is loaded and ignored
-            const uint32_t* p = partials + (size_t)wg * (NC + 1) * cols;
+            const uint32_t* p = partials + (size_t)wg * (NC + 4) * cols;
             meta[u] = p[(size_t)NC * cols + c];
             m[u] = p[c];
             g[u] = p[(size_t)cols + c];
             cm[u] = p[(size_t)2 * cols + c];
             n4[u] = NC > 3 ? p[(size_t)3 * cols + c] : 0u;
+            am[u] = p[(size_t)(NC + 1) * cols + c];
+            acm[u] = p[(size_t)(NC + 2) * cols + c];
+            meta2[u] = p[(size_t)(NC + 3) * cols + c];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (wg0 + 4 * u >= wg_hi) break;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) base[k] += (meta[u] & 3u) == (uint32_t)k ? m[u] : 0u;  // m > 0 implies a valid guide base
+            for (int k = 0; k < 4; ++k)  // a count > 0 implies a valid base in that plane set
+                base[k] += ((meta[u] & 3u) == (uint32_t)k ? m[u] : 0u) + ((meta2[u] & 3u) == (uint32_t)k ? am[u] : 0u);
             gap += g[u];
             nn += n4[u];
-            if (cm[u]) {
-                const int idx = (int)((meta[u] >> 8) & 63u);
-                if (idx != cod_idx) {
-                    if (cod_sum) atomicAdd(&codon[(size_t)c * 64 + cod_idx], cod_sum);
-                    cod_idx = idx;
-                    cod_sum = 0;
-                }
-                cod_sum += cm[u];
-            }
+            add_codon(0, meta[u], cm[u]);
+            add_codon(1, meta2[u], acm[u]);
         }
     }
 #pragma unroll
@@ -1017,7 +1116,9 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const uint32_t* __re
         if (base[k]) atomicAdd(&nuc[(size_t)c * 6 + k], base[k]);
     if (gap) atomicAdd(&nuc[(size_t)c * 6 + 4], gap);
     if (nn) atomicAdd(&nuc[(size_t)c * 6 + 5], nn);
-    if (cod_sum) atomicAdd(&codon[(size_t)c * 64 + cod_idx], cod_sum);
+#pragma unroll
+    for (int set = 0; set < 2; ++set)
+        if (cod_sum[set]) atomicAdd(&codon[(size_t)c * 64 + cod_idx[set]], cod_sum[set]);
 }
 
 typedef void (*pileup_kernel_fn)(StreamArgs);
@@ -1134,7 +1235,15 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
       for (size_t ph0 = 0; ph0 < (phase ? ph_pos.size() : 1); ph0 += kMaxPhasePositions) {
         const int ph_n = phase ? (int)std::min<size_t>(kMaxPhasePositions, ph_pos.size() - ph0) : 0;
         const size_t wave_lds = (size_t)kRows * RD * 16 + (size_t)((kRows * G * 2 + 15) / 16) * 16;  // rows + deviation queue
-        const size_t shared_lds = 16 + std::max((size_t)(G + 3) * 16, (size_t)ph_n * 8);                 // batch counter, then guide words / position pairs
+        // batch counter; then guide + alt haplotype words, or the phasing position pairs; then (pileup, when it costs
+        // no wave) one alt counter per slab column
+        const size_t guide_lds = 16 + std::max((size_t)(G + 3) * 32, (size_t)ph_n * 8);
+        const int max_waves_probe = max_waves_of(np_kernel, passes);
+        const size_t alt_lds = (size_t)G * 32 * 4;
+        const bool alt_on = !MSQ_NO_ALT && !phase && std::min<size_t>(max_waves_probe, (160 * 1024 - guide_lds - alt_lds - 512) / wave_lds) ==
+                                          std::min<size_t>(max_waves_probe, (160 * 1024 - guide_lds - 512) / wave_lds);
+        const size_t shared_lds = guide_lds + (alt_on ? alt_lds : 0);
+        a.alt_on = alt_on ? 1u : 0u;
         // waves per workgroup: as many as fit one CU (LDS, 2-3 waves per SIMD), one workgroup per CU
         const int max_waves = max_waves_of(np_kernel, passes);
         const int nwv = (int)std::min<size_t>(max_waves, (160 * 1024 - shared_lds - 512) / wave_lds);
@@ -1167,8 +1276,9 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
             const size_t lds = std::max((size_t)w * wave_lds + shared_lds, (phase || np_kernel) ? (size_t)0 : (size_t)NC * w * kLevels * 256);
             a.partials = nullptr;
             if (!phase) {
-                // scratch: partials [n_wg][NC + 1][G*32] (counts per counter, then the workgroup's guide bins per column)
-                const size_t need = (size_t)ctx->n_cu * (NC + 1) * Gslab * 32 * 4;
+                // scratch: partials [n_wg][NC + 4][G*32] (counts per counter, the workgroup's guide bins per column, the alt
+                // haplotype's nucleotide and codon counts and its bins)
+                const size_t need = (size_t)ctx->n_cu * (NC + 4) * Gslab * 32 * 4;
                 void* s = fixed_partials;
                 if (fixed_partials) {
                     if (need > fixed_bytes)
@@ -1222,7 +1332,7 @@ int msq_pileup_stream_slab_launch(msq_ctx* ctx, const msq_packed_reads& R, const
 // runtime call: `scratch` itself is a host-side handle here, not a device address.
 constexpr int kNoallocMaxColumns = 4096;  // one column slab
 constexpr int kNoallocMaxCU = 256;
-constexpr size_t kNoallocWords = (size_t)kNoallocMaxCU * 5 * kNoallocMaxColumns;  // [n_cu][NC + 1 <= 5][columns] u32 = 20 MiB
+constexpr size_t kNoallocWords = (size_t)kNoallocMaxCU * 8 * kNoallocMaxColumns;  // [n_cu][NC + 4 <= 8][columns] u32 = 32 MiB
 static __device__ __align__(256) uint32_t scratch[kNoallocWords];
 
 int msq_noalloc_init(msq_ctx* ctx)  // the context's device is current

@@ -112,6 +112,15 @@ static void DumpPhase(const char* name, Juliet::AminoAcidCaller& aac)
 
 int main()
 {
+    // MSQ_TEST_COMM=1: the same run as the one rank of a "sharded" sample -- the library's RCCL communicator, the
+    // share rule, the bounds / count all-reduces and the all-gather of the phasing keys are all on the path, and
+    // every line of the dump must be what the plain run prints
+    if (std::getenv("MSQ_TEST_COMM")) {
+        uint8_t id[MSQ_COMM_ID_BYTES];
+        Msq::Check(msq_comm_unique_id(id));
+        Msq::SetCommunicator(0, 1, id);
+        std::fprintf(stderr, "communicator: rank %d of %d\n", Msq::CommRank(), Msq::CommWorld());
+    }
     // FisherTest.EquivalentWithR
     for (int i = 0; i <= 100; ++i) std::printf("FISHER %d %.17g\n", i, Statistics::Fisher::fisher_exact_tiss(i, 1000, 10, 1000));
 

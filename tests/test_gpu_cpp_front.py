@@ -99,6 +99,21 @@ def dump():
     return d
 
 
+def test_one_rank_communicator_changes_nothing():
+    """The front as the one rank of a sharded sample (Msq::SetCommunicator: RCCL communicator, share rule, bounds and
+    count all-reduces, all-gather of the phasing keys -- SURVEY 8e behind the class interface): byte-identical dump."""
+    env = dict(os.environ)
+    for k in ("DELQV", "SUBQV", "INSQV", "QUALQV"):
+        env.pop(k, None)
+    plain = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env)
+    env["MSQ_TEST_COMM"] = "1"
+    comm = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env)
+    assert plain.returncode == 0 and comm.returncode == 0, comm.stderr[-2000:]
+    assert "communicator: rank 0 of 1" in comm.stderr
+    keep = lambda text: [l for l in text.splitlines() if not l.startswith(("RCCL version", "HIP version", "ROCm version", "Hostname", "Librccl"))]
+    assert keep(comm.stdout) == keep(plain.stdout) and len(plain.stdout) > 100000
+
+
 def to_reads(recs, rich):
     rows = []
     for start, end, cig, nuc, qs in recs:
