@@ -83,6 +83,7 @@ struct StreamArgs {
     int32_t RD;          // words per LDS row: a margin word, the slab's G words, two margin words, a zero pad word
     uint32_t normalized; // MSQ_READS_NORMALIZED: consuming bases lead every group, no compaction needed
     uint32_t alt_on;     // the launch has LDS for the alt-haplotype counters (one u32 per slab column)
+    uint32_t flush_wide; // the LDS holds the counter levels of all passes at once (flush in one round)
     uint32_t* nuc;
     uint32_t* codon;
     uint32_t* partials;  // [gridDim.x][NC + 4][G*32]
@@ -140,6 +141,24 @@ __device__ __forceinline__ uint32_t ripple(uint32_t (&cnt)[kLevels], uint32_t ca
         carry = c;
     }
     return carry;
+}
+
+// a[l] bit c -> a[c & 15] bit l (+ 16 for c >= 16): the 16 x 16 bit matrices in the low and the high halves of the 16
+// words are transposed, both at once (block swaps of 8, 4, 2, 1)
+__device__ __forceinline__ void transpose16x2(uint32_t (&a)[16])
+{
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int j = 8 >> s;
+        const uint32_t m = s == 0 ? 0x00FF00FFu : s == 1 ? 0x0F0F0F0Fu : s == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (!(k & j)) {
+                const uint32_t t = ((a[k] >> j) ^ a[k + j]) & m;
+                a[k] ^= t << j;
+                a[k + j] ^= t;
+            }
+    }
 }
 
 // bit-sliced compare: 2 * a > b, per column
@@ -980,42 +999,62 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     constexpr bool SLICED_FLUSH = NP == 0;
     if constexpr (SLICED_FLUSH) {
         constexpr int SL = kLevels + 5;  // levels of a sum over <= 16 waves x 2 row halves
-        uint32_t* const slab = lds;      // [NC][NWV][kLevels][64] (the launcher sizes the LDS for it; rows and guide are dead)
-    #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            __syncthreads();  // the guide words / the previous pass's sums have been read
-    #pragma unroll
-            for (int k = 0; k < NC; ++k)
-    #pragma unroll
-                for (int l = 0; l < kLevels; ++l) slab[((k * NWV + wave) * kLevels + l) * 64 + lane] = cnt[p][k][l];
-            __syncthreads();
-            // in a split pass lanes L and L + 32 counted different rows of the same word: two entries per wave
-            const bool sp = p == PASSES - 1 && split;
-            const bool mine = act[p] && (!sp || lane < 32);
-            for (int k = wave; k < NC && !(MSQ_EXP & 32); k += NWV) {  // wave-uniform
-                uint32_t sum[SL];
-    #pragma unroll
-                for (int l = 0; l < SL; ++l) sum[l] = 0;
-                for (int e = 0; e < (sp ? 2 * NWV : NWV); ++e) {
-                    const uint32_t* src = slab + (k * NWV + (sp ? e >> 1 : e)) * kLevels * 64 + ((lane + (sp ? 32 * (e & 1) : 0)) & 63);
-                    uint32_t carry = 0;
-    #pragma unroll
-                    for (int l = 0; l < SL; ++l) csa(sum[l], l < kLevels ? src[l * 64] : 0u, carry, sum[l], carry);
+        uint32_t* const slab = lds;      // [passes of the round][NC][NWV][kLevels][64] (the launcher sizes the LDS; rows and guide are dead)
+        // One round: the waves park the levels of passes [p_lo, p_hi) in LDS, then every (counter, pass) pair is one job
+        // -- add the waves' entries up, transpose, store -- and the jobs are dealt out over the waves.  With room for
+        // all passes at once (a.flush_wide) there is a single round and PASSES * NC jobs run side by side.
+        auto round = [&](const int p_lo, const int p_hi) {
+            __syncthreads();  // the guide words / the previous round's sums have been read
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p)
+                if (p >= p_lo && p < p_hi) {
+#pragma unroll
+                    for (int k = 0; k < NC; ++k)
+#pragma unroll
+                        for (int l = 0; l < kLevels; ++l)
+                            slab[((((p - p_lo) * NC + k) * NWV + wave) * kLevels + l) * 64 + lane] = cnt[p][k][l];
                 }
-                if (mine) {
-                    uint4* dst = reinterpret_cast<uint4*>(part + (size_t)k * cols + cgp[p] * 32);
-                    for (int j = 0; j < 32; j += 4) {
-                        uint32_t v[4] = {0, 0, 0, 0};
-    #pragma unroll
-                        for (int l = 0; l < SL; ++l) {
-                            const uint32_t nib = (sum[l] >> j) & 15u;
-    #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] |= ((nib >> i) & 1u) << l;
+            __syncthreads();
+            for (int job = wave; job < NC * (p_hi - p_lo) && !(MSQ_EXP & 32); job += NWV) {  // wave-uniform
+                const int k = job % NC, pj = p_lo + job / NC;
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) {
+                    if (p != pj) continue;
+                    // in a split pass lanes L and L + 32 counted different rows of the same word: two entries per wave
+                    const bool sp = p == PASSES - 1 && split;
+                    const bool mine = act[p] && (!sp || lane < 32);
+                    const uint32_t* const base = slab + (size_t)((p - p_lo) * NC + k) * NWV * kLevels * 64;
+                    uint32_t sum[SL];
+#pragma unroll
+                    for (int l = 0; l < SL; ++l) sum[l] = 0;
+                    for (int e = 0; e < (sp ? 2 * NWV : NWV); ++e) {
+                        const uint32_t* src = base + (sp ? e >> 1 : e) * kLevels * 64 + ((lane + (sp ? 32 * (e & 1) : 0)) & 63);
+                        uint32_t carry = 0;
+#pragma unroll
+                        for (int l = 0; l < SL; ++l) csa(sum[l], l < kLevels ? src[l * 64] : 0u, carry, sum[l], carry);
+                    }
+                    if (mine) {
+                        // bit-sliced sum -> 32 column counts: the levels are the rows of two 16 x 16 bit matrices side
+                        // by side (columns 0..15 | 16..31), transposed together in four swap stages
+                        static_assert(SL <= 16, "the transposition holds 16 levels");
+                        uint32_t t16[16];
+#pragma unroll
+                        for (int l = 0; l < 16; ++l) t16[l] = l < SL ? sum[l] : 0u;
+                        transpose16x2(t16);
+                        uint4* dst = reinterpret_cast<uint4*>(part + (size_t)k * cols + cgp[p] * 32);
+#pragma unroll
+                        for (int r = 0; r < 16; r += 4) {
+                            dst[r >> 2] = make_uint4(t16[r] & 0xffffu, t16[r + 1] & 0xffffu, t16[r + 2] & 0xffffu, t16[r + 3] & 0xffffu);
+                            dst[4 + (r >> 2)] = make_uint4(t16[r] >> 16, t16[r + 1] >> 16, t16[r + 2] >> 16, t16[r + 3] >> 16);
                         }
-                        dst[j >> 2] = make_uint4(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
+        };
+        if (a.flush_wide) {
+            round(0, PASSES);
+        } else {
+            for (int p = 0; p < PASSES; ++p) round(p, p + 1);
         }
     } else {
         uint32_t* const acc = lds;  // [cols], over the rows (no wave needs them any more)
@@ -1273,7 +1312,10 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
                 n_wg = (int)((n_batches + w - 1) / w);
             }
             // the flush of the kernels without QV planes adds the waves' counters up through LDS: [NC][w][kLevels][64] words
-            const size_t lds = std::max((size_t)w * wave_lds + shared_lds, (phase || np_kernel) ? (size_t)0 : (size_t)NC * w * kLevels * 256);
+            const size_t slab_lds = (phase || np_kernel) ? (size_t)0 : (size_t)NC * w * kLevels * 256;  // one pass's levels
+            const bool flush_wide = slab_lds * passes <= 160 * 1024 - 512;
+            a.flush_wide = flush_wide ? 1u : 0u;
+            const size_t lds = std::max((size_t)w * wave_lds + shared_lds, flush_wide ? slab_lds * passes : slab_lds);
             a.partials = nullptr;
             if (!phase) {
                 // scratch: partials [n_wg][NC + 4][G*32] (counts per counter, the workgroup's guide bins per column, the alt
