@@ -6,8 +6,9 @@
 
 A step is one pass of the hot path over one batch of synthetic reads already resident in HBM:
 
-  window bounds of the shard + cleared count matrices (one launch, msq_pileup_begin)
-  -> pileup of the shard inside the sample's window (nucleotide + codon counts; stream kernel + fold)
+  window bounds of the shard + cleared count matrices + pileup of the shard inside the sample's window (nucleotide
+  + codon counts): ONE call, msq_pileup_step -- the stream kernel (the bounds are its side product) + its fold, which
+  stores the matrices (--unfused: msq_pileup_begin, then msq_pileup: a bounds / clearing launch of its own)
   -> [N > 1: ONE RCCL group over xGMI -- MAX of the bounds, u32 SUM of the count matrices; the library's own
      communicator, msq_comm_*]
   -> CountNumberOfTests + per-(position, codon) Fisher cells, replicated on every rank.
@@ -57,6 +58,7 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "simple", "stream"])
     ap.add_argument("--window", default="known", choices=["known", "device", "host"], help="see the module docstring")
     ap.add_argument("--host-bounds", action="store_true", help="= --window host")
+    ap.add_argument("--unfused", action="store_true", help="msq_pileup_begin + msq_pileup instead of msq_pileup_step")
     ap.add_argument("--no-partition", action="store_true", help="windows wider than 4096 columns: run every slab launch "
                     "over the whole read set instead of over the column-slab partition built at set-up")
     ap.add_argument("--slab-columns", type=int, default=0, help="widest column slab of the partition (multiple of 32, "
@@ -207,11 +209,14 @@ class Run:
         L, abi, ctx, dr, ex = self.L, self.abi, self.ctx, self.dr, self.ex
         if self.flow == "known":
             # bounds of the shard + cleared matrices in one launch; the pileup inside the sample's window; one RCCL group
-            abi.check(L.msq_pileup_begin(ctx.h, dr.view, self.bounds.data_ptr(), self.counts.data_ptr(), self.counts.numel()))
-            if self.part:
-                abi.check(L.msq_pileup_partition(ctx.h, self.part._h, self.thr, self.nuc.data_ptr(), self.codon.data_ptr()))
-            else:
-                abi.check(L.msq_pileup(ctx.h, dr.view, self.thr, self.b0, self.W, self.nuc.data_ptr(), self.codon.data_ptr(), self.mode))
+            if self.part or self.mode != abi.MSQ_PILEUP_AUTO or self.a.unfused:
+                abi.check(L.msq_pileup_begin(ctx.h, dr.view, self.bounds.data_ptr(), self.counts.data_ptr(), self.counts.numel()))
+                if self.part:
+                    abi.check(L.msq_pileup_partition(ctx.h, self.part._h, self.thr, self.nuc.data_ptr(), self.codon.data_ptr()))
+                else:
+                    abi.check(L.msq_pileup(ctx.h, dr.view, self.thr, self.b0, self.W, self.nuc.data_ptr(), self.codon.data_ptr(), self.mode))
+            else:  # the same as one call: the bounds come out of the pileup kernel, its fold stores the matrices
+                abi.check(L.msq_pileup_step(ctx.h, dr.view, self.thr, self.b0, self.W, self.bounds.data_ptr(), self.counts.data_ptr()))
             ex.allreduce_step(self.bounds, self.counts)
         elif self.flow == "device":  # the window discovered on the device: nothing in the step waits for the host
             abi.check(L.msq_window_bounds_device(ctx.h, dr.view, self.bounds.data_ptr()))

@@ -193,6 +193,16 @@ int msq_window_bounds_device(msq_ctx* ctx, const msq_packed_reads* d_reads, int3
  * = 0, typically the caller's [W][6] and [W][64] matrices in one buffer.  Async. */
 int msq_pileup_begin(msq_ctx* ctx, const msq_packed_reads* d_reads, int32_t* d_bounds, uint32_t* d_counts, size_t n_words);
 
+/* MSAByRow's constructor + MSAByColumn + CodonsAt (src/MSA.cpp:55-92,94-136,144-219) for a caller that knows its
+ * window beforehand, as ONE call: what msq_pileup_begin followed by msq_pileup(.., MSQ_PILEUP_AUTO) leave --
+ * d_bounds = {-begin0, end0} of these reads, d_counts = [W][6] nucleotide counts followed by [W][64] codon counts,
+ * OVERWRITTEN (not added to) with the pileup inside [win_begin0, win_begin0 + W).  When the streaming kernel can
+ * take the whole call as one launch (W <= 4096, no exotic ops, ~2 M reads on 256 CUs) there is no bounds and no
+ * clearing launch: the bounds are a side product of the kernel and its fold stores.  Otherwise exactly the two
+ * calls above.  The context keeps a [W][70] u32 matrix of its own for this (grown on demand).  Async. */
+int msq_pileup_step(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
+                    int32_t W, int32_t* d_bounds, uint32_t* d_counts);
+
 /* MSAByRow::MSAByRow + MSAByColumn::MSAByColumn + MSAByRow::CodonsAt for every column
  * (src/MSA.cpp:55-92, 94-136, 144-219) as two dense count matrices, ADDED into the caller's buffers:
  *   d_nuc  [W][6]  u32, bins A C G T - N            == MSAColumn::counts_ (MSA.h:194)

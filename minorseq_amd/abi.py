@@ -120,6 +120,7 @@ _SIGNATURES = {
     "msq_pileup_check": (C.c_int, [_P]),
     "msq_phase_codons": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "msq_pileup_begin": (C.c_int, [_P, C.POINTER(PackedReads), _P, _P, C.c_size_t]),
+    "msq_pileup_step": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P]),
     "msq_timing_enable_strided": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "msq_timing_read_path": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
     "msq_comm_unique_id": (C.c_int, [_P]),

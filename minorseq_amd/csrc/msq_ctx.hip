@@ -80,6 +80,7 @@ extern "C" int msq_ctx_destroy(msq_ctx* ctx)
     if (ctx->d_err) (void)hipFree(ctx->d_err);
     if (ctx->d_lfact) (void)hipFree(ctx->d_lfact);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_dev) (void)hipFree(ctx->d_dev);
     for (int k = 0; k < 2; ++k) {
         if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
         if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);

@@ -28,7 +28,7 @@ struct msq_ctx {
     // [48] small accumulators of kernels that finish their own reduction: all zero between kernels -- the last
     // workgroup of a kernel (atomic ticket) reads the result, hands it on and clears what it used, so no memset
     // and no finishing kernel is launched.  [0..2] window bounds (keyed maxima, ticket), [4..5] their decoded
-    // result for the host, [8..9] number of tests (sum, ticket)
+    // result for the host, [8..9] number of tests (sum, ticket), [16..18] the bounds inside msq_pileup_step's kernel
     uint32_t* d_small = nullptr;
     double* d_lfact = nullptr;      // [lfact_n + 1] lgamma(n + 1.0)
     int64_t lfact_n = -1;
@@ -43,6 +43,11 @@ struct msq_ctx {
     // msq_pileup_noalloc: this GPU's copy of the built-in scratch array (resolved once, at context creation)
     uint32_t* d_noalloc = nullptr;
     size_t noalloc_bytes = 0;
+    // msq_pileup_step: the matrix its kernel's deviation path adds into ([W * 70], grown on demand); all zero between
+    // calls (the fold stores matrix + partials into the caller's buffer and clears it), dev_clean says so
+    uint32_t* d_dev = nullptr;
+    size_t dev_words = 0;
+    bool dev_clean = false;
     // measurement aid: event pairs around the dominant pileup kernel (msq_timing_enable)
     // and, for the same records, the end of the step's last kernel (msq_call_cells): K1 .. K2 as SURVEY 8d prices it.
     // stride: only every stride-th pileup is timed (an event costs the stream a ~5 us bubble)

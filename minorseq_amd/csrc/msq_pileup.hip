@@ -12,6 +12,8 @@
 int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr,
                              int32_t win_begin0, int32_t W, const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon,
                              bool* handled);
+int msq_pileup_stream_step_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
+                                  int32_t* d_bounds, uint32_t* d_counts, bool* handled);
 
 // ------------------------------------------------------------------------------------------ window bounds
 // MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:138-142).  acc[0] = max over reads of ~key(start),
@@ -229,6 +231,29 @@ extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const m
             return msq_fail(MSQ_ERR_ARG, "msq_pileup: streaming kernel not applicable (W=%d, flags=%u)", W, d_reads->flags);
     }
     return launch_simple(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon, d_reads->n_reads);
+}
+
+// msq_pileup_begin + msq_pileup(AUTO) as ONE call: the reads' bounds into d_bounds, the matrices d_counts = [W][6]
+// nucleotide counts then [W][64] codon counts OVERWRITTEN with the pileup inside [win_begin0, win_begin0 + W).
+// When the streaming kernel can take the whole call as one launch, it is one kernel + its fold (the bounds are a
+// side product of the kernel, the fold stores instead of adding: no bounds / clearing launch at all).
+extern "C" int msq_pileup_step(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
+                               int32_t W, int32_t* d_bounds, uint32_t* d_counts)
+{
+    if (!ctx || !d_reads || !thr || !d_bounds) return msq_fail(MSQ_ERR_ARG, "msq_pileup_step: NULL argument");
+    if (W < 0) return msq_fail(MSQ_ERR_ARG, "msq_pileup_step: negative window width %d", W);
+    if (W > 0 && !d_counts) return msq_fail(MSQ_ERR_ARG, "msq_pileup_step: NULL count matrices");
+    if (d_reads->n_reads && (!d_reads->ref_start || !d_reads->ref_end)) return msq_fail(MSQ_ERR_ARG, "msq_pileup_step: NULL ref arrays");
+    const size_t n_words = (size_t)W * 70;
+    if (d_reads->n_reads == 0 || W == 0) return msq_pileup_begin(ctx, d_reads, d_bounds, d_counts, n_words);
+    if (int rc = msq_validate_reads(d_reads, thr, "msq_pileup_step")) return rc;
+    MSQ_HIP(hipSetDevice(ctx->device));
+    bool handled = false;
+    int rc = msq_pileup_stream_step_launch(ctx, *d_reads, *thr, win_begin0, W, d_bounds, d_counts, &handled);
+    if (rc != MSQ_OK || handled) return rc;
+    rc = msq_pileup_begin(ctx, d_reads, d_bounds, d_counts, n_words);
+    if (rc != MSQ_OK) return rc;
+    return msq_pileup(ctx, d_reads, thr, win_begin0, W, d_counts, d_counts + (size_t)W * 6, MSQ_PILEUP_AUTO);
 }
 
 extern "C" int msq_pileup_device_window(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,

@@ -93,6 +93,10 @@ struct StreamArgs {
     const int32_t* ph_idx;  // [ph_n] their index k in the caller's position list
     int32_t ph_n, ph_total; // positions of this launch, of the caller's list (the key row length)
     uint16_t* ph_keys;      // [n_reads][ph_total]
+    // msq_pileup_step: the shard's bounds come out of this launch too (NULL otherwise)
+    const int32_t* ref_end;
+    uint32_t* bounds_acc;   // {max of ~begin, max of end, workgroups done}, order-encoded; left at zero
+    int32_t* bounds_out;    // {-begin0, end0}
 };
 
 __device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int k)  // bits k.. of the 64-bit hi:lo
@@ -612,6 +616,18 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     };
     zero_rows();
     if (tid == 0) *draw_ctr = 0;
+    // (msq_pileup_step) this workgroup's share of the shard's reads for the window bounds: the loads go out first,
+    // they are looked at once the first batch's chunk loads are under way
+    int32_t b_lo = INT32_MAX, b_hi = INT32_MIN;
+    const bool with_bounds = !PHASE && a.bounds_acc != nullptr;
+    if (with_bounds) {
+        if (tid < 2) draw_ctr[1 + tid] = 0;
+#pragma unroll 4
+        for (uint64_t i = a.read_lo + (uint64_t)blockIdx.x * T + tid; i < a.read_hi; i += (uint64_t)gridDim.x * T) {
+            b_lo = min(b_lo, a.ref_start[i]);
+            b_hi = max(b_hi, a.ref_end[i]);
+        }
+    }
     if (PHASE) {  // the guide area holds the position list instead: (window column, key index) pairs
         for (int i = tid; i < a.ph_n; i += T) {
             gl[2 * i] = (uint32_t)a.ph_pos[i];
@@ -924,11 +940,35 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     // the only workgroup barriers before the flush: a wave without reads meets them too), and only then do the
     // counters come to life, so nothing but the load slots is live across the call.
     bool have = cs.live;
+    if (with_bounds) {  // wave maxima (order-preserving unsigned codes) meet in LDS; the barriers of learn_guide publish them
+        uint32_t k_lo = ~((uint32_t)b_lo ^ 0x80000000u), k_hi = (uint32_t)b_hi ^ 0x80000000u;
+        for (int d = 32; d >= 1; d >>= 1) {
+            k_lo = max(k_lo, (uint32_t)__shfl_xor((int)k_lo, d));
+            k_hi = max(k_hi, (uint32_t)__shfl_xor((int)k_hi, d));
+        }
+        if (lane == 0) {
+            atomicMax(&draw_ctr[1], k_lo);
+            atomicMax(&draw_ctr[2], k_hi);
+        }
+    }
     MSQ_TR();
     if (have) chunks();
     MSQ_TR();
     if (!PHASE) {
         learn_guide();
+        if (with_bounds && tid == 0) {  // one atomic pair per workgroup; the last workgroup in publishes and clears
+            atomicMax(&a.bounds_acc[0], draw_ctr[1]);
+            atomicMax(&a.bounds_acc[1], draw_ctr[2]);
+            __threadfence();
+            if (atomicAdd(&a.bounds_acc[2], 1u) == gridDim.x - 1) {
+                __threadfence();
+                const uint32_t k_lo = atomicExch(&a.bounds_acc[0], 0u), k_hi = atomicExch(&a.bounds_acc[1], 0u);
+                atomicExch(&a.bounds_acc[2], 0u);
+                const int32_t begin0 = (int32_t)(~k_lo ^ 0x80000000u), end0 = (int32_t)(k_hi ^ 0x80000000u);
+                a.bounds_out[0] = -begin0;
+                a.bounds_out[1] = end0 > 0 ? end0 : 0;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p)
 #pragma unroll
@@ -1095,69 +1135,108 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
 }
 
 // Fold the workgroup partials into the count matrices: matches go to each workgroup's guide nucleotide / codon
-// bin, gaps to '-', Ns to 'N' (bins 4 and 5, NucleotideConversion.h:69-88).  Block = 64 columns x 4 workgroup
-// lanes; blockIdx.y slices the workgroups further.
-__global__ __launch_bounds__(256) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
-                                                            int col0, int W, uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon)
+// bin, gaps to '-', Ns to 'N' (bins 4 and 5, NucleotideConversion.h:69-88).  Block = 32 columns x 32 workgroup
+// lanes: a thread has the loads of eight workgroups' partials in flight at once (the kernel is latency-bound: one
+// trip for 256 workgroups), the 32 lanes of a column meet in LDS, and what is not zero there leaves as one global
+// atomic per bin.  blockIdx.y slices the workgroups further (more blocks, but as many more global atomics).
+constexpr int kFoldCols = 32, kFoldSubs = 32, kFoldTrip = 8;
+__global__ __launch_bounds__(kFoldCols* kFoldSubs) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
+                                                                             int col0, int W, uint32_t* __restrict__ nuc,
+                                                                             uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
+                                                                             uint32_t* __restrict__ dev_codon)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);  // column of the slab; col0 + c = column of the window
-    const int sub = threadIdx.x >> 6;
+    constexpr int kCodStride = 65, kNucStride = 7;  // odd strides: the lanes of a wave are columns
+    __shared__ uint32_t cod_acc[kFoldCols * kCodStride];
+    __shared__ uint32_t nuc_acc[kFoldCols * kNucStride];
+    const int T = kFoldCols * kFoldSubs, tid = threadIdx.x;
+    for (int i = tid; i < kFoldCols * kCodStride; i += T) cod_acc[i] = 0;
+    for (int i = tid; i < kFoldCols * kNucStride; i += T) nuc_acc[i] = 0;
+    const int cl = tid & (kFoldCols - 1), sub = tid / kFoldCols;
+    const int c = blockIdx.x * kFoldCols + cl;  // column of the slab; col0 + c = column of the window
     const int per = (n_wg + gridDim.y - 1) / gridDim.y;
     const int wg_lo = blockIdx.y * per, wg_hi = min(n_wg, wg_lo + per);
-    if (c >= cols || col0 + c >= W) return;
-    nuc += (size_t)col0 * 6;
-    codon += (size_t)col0 * 64;
-    uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0;
-    // codon counts: runs of workgroups that agree on the bin are added up before they cost an atomic (set 0 = the
-    // guide's codon, set 1 = the alt haplotype's)
-    uint32_t cod_sum[2] = {0, 0};
-    int cod_idx[2] = {-1, -1};
-    auto add_codon = [&](int set, uint32_t meta, uint32_t n) {
-        if (!n) return;
-        const int idx = (int)((meta >> 8) & 63u);
-        if (idx != cod_idx[set]) {
-            if (cod_sum[set]) atomicAdd(&codon[(size_t)c * 64 + cod_idx[set]], cod_sum[set]);
-            cod_idx[set] = idx;
-            cod_sum[set] = 0;
-        }
-        cod_sum[set] += n;
-    };
-    // four workgroups' partials per trip, all their loads in flight together (the kernel is latency-bound)
-    for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += 16) {
-        uint32_t meta[4], m[4], g[4], cm[4], n4[4], am[4], acm[4], meta2[4];
+    const bool valid = c < cols && col0 + c < W;
+    __syncthreads();
+    if (valid) {
+        uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0;
+        // codon counts: runs of workgroups that agree on the bin are added up before they cost an atomic (set 0 = the
+        // guide's codon, set 1 = the alt haplotype's)
+        uint32_t cod_sum[2] = {0, 0};
+        int cod_idx[2] = {-1, -1};
+        auto add_codon = [&](int set, uint32_t meta, uint32_t n) {
+            if (!n) return;
+            const int idx = (int)((meta >> 8) & 63u);
+            if (idx != cod_idx[set]) {
+                if (cod_sum[set]) atomicAdd(&cod_acc[cl * kCodStride + cod_idx[set]], cod_sum[set]);
+                cod_idx[set] = idx;
+                cod_sum[set] = 0;
+            }
+            cod_sum[set] += n;
+        };
+        for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += kFoldSubs * kFoldTrip) {
+            uint32_t meta[kFoldTrip], m[kFoldTrip], g[kFoldTrip], cm[kFoldTrip], n4[kFoldTrip], am[kFoldTrip], acm[kFoldTrip], meta2[kFoldTrip];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int wg = min(wg0 + 4 * u, wg_hi - 1);  // clamped: a slot past the end is loaded and ignored
-            const uint32_t* p = partials + (size_t)wg * (NC + 4) * cols;
-            meta[u] = p[(size_t)NC * cols + c];
-            m[u] = p[c];
-            g[u] = p[(size_t)cols + c];
-            cm[u] = p[(size_t)2 * cols + c];
-            n4[u] = NC > 3 ? p[(size_t)3 * cols + c] : 0u;
-            am[u] = p[(size_t)(NC + 1) * cols + c];
-            acm[u] = p[(size_t)(NC + 2) * cols + c];
-            meta2[u] = p[(size_t)(NC + 3) * cols + c];
+            for (int u = 0; u < kFoldTrip; ++u) {
+                const int wg = min(wg0 + kFoldSubs * u, wg_hi - 1);  // clamped: a slot past the end is loaded and ignored
+                const uint32_t* p = partials + (size_t)wg * (NC + 4) * cols;
+                meta[u] = p[(size_t)NC * cols + c];
+                m[u] = p[c];
+                g[u] = p[(size_t)cols + c];
+                cm[u] = p[(size_t)2 * cols + c];
+                n4[u] = NC > 3 ? p[(size_t)3 * cols + c] : 0u;
+                am[u] = p[(size_t)(NC + 1) * cols + c];
+                acm[u] = p[(size_t)(NC + 2) * cols + c];
+                meta2[u] = p[(size_t)(NC + 3) * cols + c];
+            }
+#pragma unroll
+            for (int u = 0; u < kFoldTrip; ++u) {
+                if (wg0 + kFoldSubs * u >= wg_hi) break;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)  // a count > 0 implies a valid base in that plane set
+                    base[k] += ((meta[u] & 3u) == (uint32_t)k ? m[u] : 0u) + ((meta2[u] & 3u) == (uint32_t)k ? am[u] : 0u);
+                gap += g[u];
+                nn += n4[u];
+                add_codon(0, meta[u], cm[u]);
+                add_codon(1, meta2[u], acm[u]);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (wg0 + 4 * u >= wg_hi) break;
+        for (int k = 0; k < 4; ++k)
+            if (base[k]) atomicAdd(&nuc_acc[cl * kNucStride + k], base[k]);
+        if (gap) atomicAdd(&nuc_acc[cl * kNucStride + 4], gap);
+        if (nn) atomicAdd(&nuc_acc[cl * kNucStride + 5], nn);
 #pragma unroll
-            for (int k = 0; k < 4; ++k)  // a count > 0 implies a valid base in that plane set
-                base[k] += ((meta[u] & 3u) == (uint32_t)k ? m[u] : 0u) + ((meta2[u] & 3u) == (uint32_t)k ? am[u] : 0u);
-            gap += g[u];
-            nn += n4[u];
-            add_codon(0, meta[u], cm[u]);
-            add_codon(1, meta2[u], acm[u]);
-        }
+        for (int set = 0; set < 2; ++set)
+            if (cod_sum[set]) atomicAdd(&cod_acc[cl * kCodStride + cod_idx[set]], cod_sum[set]);
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (base[k]) atomicAdd(&nuc[(size_t)c * 6 + k], base[k]);
-    if (gap) atomicAdd(&nuc[(size_t)c * 6 + 4], gap);
-    if (nn) atomicAdd(&nuc[(size_t)c * 6 + 5], nn);
-#pragma unroll
-    for (int set = 0; set < 2; ++set)
-        if (cod_sum[set]) atomicAdd(&codon[(size_t)c * 64 + cod_idx[set]], cod_sum[set]);
+    __syncthreads();
+    const int cb = col0 + blockIdx.x * kFoldCols;  // window column of the block's column 0
+    nuc += (size_t)cb * 6;
+    codon += (size_t)cb * 64;
+    if (dev_nuc) {
+        // msq_pileup_step: this block is the only writer of its columns (gridDim.y == 1, one launch): the matrices are
+        // STORED -- the fold's sums plus what the deviation path added to its own matrix, which is handed back cleared
+        dev_nuc += (size_t)cb * 6;
+        dev_codon += (size_t)cb * 64;
+        const int ncol = min(kFoldCols, min(cols - blockIdx.x * kFoldCols, W - cb));
+        for (int i = tid; i < ncol * 64; i += T) {
+            codon[i] = cod_acc[(i >> 6) * kCodStride + (i & 63)] + dev_codon[i];
+            dev_codon[i] = 0;
+        }
+        for (int i = tid; i < ncol * 6; i += T) {
+            nuc[i] = nuc_acc[(i / 6) * kNucStride + i % 6] + dev_nuc[i];
+            dev_nuc[i] = 0;
+        }
+        return;
+    }
+    for (int i = tid; i < kFoldCols * 64; i += T) {  // only columns that were valid hold anything
+        const uint32_t v = cod_acc[(i >> 6) * kCodStride + (i & 63)];
+        if (v) atomicAdd(&codon[i], v);
+    }
+    for (int i = tid; i < kFoldCols * 6; i += T) {
+        const uint32_t v = nuc_acc[(i / 6) * kNucStride + i % 6];
+        if (v) atomicAdd(&nuc[i], v);
+    }
 }
 
 typedef void (*pileup_kernel_fn)(StreamArgs);
@@ -1198,11 +1277,20 @@ void msq_slab_layout(int32_t W, int max_words, int* n_slabs, int* Gslab)
     *Gslab = *n_slabs ? (Gtot + *n_slabs - 1) / *n_slabs : 0;
 }
 
+// msq_pileup_step: bounds, cleared matrices and the pileup from one kernel + its fold.  Only when the whole call is
+// ONE launch (one column slab, every read in it); otherwise the launch reports "not handled" and the caller takes
+// the separate calls.
+struct FusedStep {
+    int32_t* d_bounds;  // out: {-begin0, end0} of the reads
+    uint32_t* d_dev;    // the context's deviation matrix [W * 70], all zero between calls
+};
+
 // fixed_partials: NULL, or a caller-provided buffer of fixed_bytes for the workgroup partials (msq_pileup_noalloc:
 // nothing is allocated then, and a launch that needs more is refused).
 static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
                          const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon, const PhaseRequest* phase, bool* handled,
-                         int only_slab = -1, int slab_words = 128, uint32_t* fixed_partials = nullptr, size_t fixed_bytes = 0)
+                         int only_slab = -1, int slab_words = 128, uint32_t* fixed_partials = nullptr, size_t fixed_bytes = 0,
+                         const FusedStep* fused = nullptr)
 {
     *handled = false;
     if (R.flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
@@ -1249,7 +1337,11 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     a.ph_pos = a.ph_idx = nullptr;
     a.ph_n = a.ph_total = 0;
     a.ph_keys = nullptr;
-    if (!phase) msq_timing_mark_begin(ctx);
+    a.ref_end = nullptr;
+    a.bounds_acc = nullptr;
+    a.bounds_out = nullptr;
+    if (fused && (n_slabs != 1 || !R.ref_end)) return MSQ_OK;
+    bool marked = false;  // the timing slot opens with the first launch
     if (only_slab >= n_slabs) return msq_fail(MSQ_ERR_ARG, "msq_pileup_slab: slab %d of %d", only_slab, n_slabs);
     for (int slab = only_slab >= 0 ? only_slab : 0; slab < (only_slab >= 0 ? only_slab + 1 : n_slabs); ++slab) {
         const int G = std::min(Gslab, Gtot - slab * Gslab);
@@ -1290,6 +1382,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
         // the pileup's counters hold 1023 reads per wave and launch; the gather has no such limit
         const uint64_t reads_per_launch = phase ? R.n_reads : (uint64_t)ctx->n_cu * nwv * kMaxBatchesPerWave * kRows;
         pileup_kernel_fn kern = phase ? pick_phase_kernel(np_kernel) : pick_kernel(np_kernel, passes, many_n);
+        if (fused && R.n_reads > reads_per_launch) return MSQ_OK;  // more than one launch: not for the fused step
         if (phase) {
             void* s = nullptr;
             int rc = msq_scratch(ctx, (size_t)ph_n * 8, &s);
@@ -1334,16 +1427,27 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
             a.read_lo = lo;
             a.read_hi = hi;
             a.n_batches = n_batches;
+            if (fused) {  // deviations into the context's matrix; the fold stores the sum and clears that matrix again
+                a.nuc = fused->d_dev;
+                a.codon = fused->d_dev + (size_t)W * 6;
+                a.ref_end = R.ref_end;
+                a.bounds_acc = ctx->d_small + 16;
+                a.bounds_out = fused->d_bounds;
+            }
+            if (!phase && !marked) {
+                msq_timing_mark_begin(ctx);
+                marked = true;
+            }
             if (lds > 48 * 1024)
                 MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
             if (!phase && last_slab && hi == R.n_reads) msq_timing_mark_end(ctx);
             MSQ_HIP(hipGetLastError());
             if (phase) continue;
-            const int col_blocks = (G * 32 + 63) / 64;
-            const int slices = std::max(1, std::min(n_wg / 32, (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
-            hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(256), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
-                               a.slab0, W, d_nuc, d_codon);
+            const int col_blocks = (G * 32 + kFoldCols - 1) / kFoldCols;
+            const int slices = fused ? 1 : std::max(1, std::min(n_wg / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
+            hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, a.partials, n_wg,
+                               NC, G * 32, a.slab0, W, d_nuc, d_codon, fused ? a.nuc : (uint32_t*)nullptr, fused ? a.codon : (uint32_t*)nullptr);
             MSQ_HIP(hipGetLastError());
         }
         if (phase) MSQ_HIP(hipStreamSynchronize(ctx->stream));  // the host position vectors and the scratch are reused
@@ -1364,6 +1468,32 @@ int msq_pileup_stream_slab_launch(msq_ctx* ctx, const msq_packed_reads& R, const
                                   int32_t W, int slab, int slab_words, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
 {
     return stream_launch(ctx, R, thr, win_begin0, W, nullptr, d_nuc, d_codon, nullptr, handled, slab, slab_words);
+}
+
+// msq_pileup_step's streaming half; *handled = false: take msq_pileup_begin + msq_pileup instead
+int msq_pileup_stream_step_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
+                                  int32_t* d_bounds, uint32_t* d_counts, bool* handled)
+{
+    *handled = false;
+    if (R.flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
+    const size_t words = (size_t)W * 70;
+    if (ctx->dev_words < words) {  // the deviation matrix: grown on demand, zero from here on (the fold hands it back cleared)
+        MSQ_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->d_dev) MSQ_HIP(hipFree(ctx->d_dev));
+        ctx->d_dev = nullptr;
+        ctx->dev_words = 0;
+        hipError_t e = hipMalloc(&ctx->d_dev, words * sizeof(uint32_t));
+        if (e != hipSuccess) return msq_fail(MSQ_ERR_NOMEM, "msq_pileup_step: hipMalloc(%zu): %s", words * sizeof(uint32_t), hipGetErrorString(e));
+        ctx->dev_words = words;
+        ctx->dev_clean = false;
+    }
+    if (!ctx->dev_clean) MSQ_HIP(hipMemsetAsync(ctx->d_dev, 0, ctx->dev_words * sizeof(uint32_t), ctx->stream));
+    ctx->dev_clean = false;  // until the fold that clears it is in the stream
+    FusedStep f{d_bounds, ctx->d_dev};
+    int rc = stream_launch(ctx, R, thr, win_begin0, W, nullptr, d_counts, d_counts + (size_t)W * 6, nullptr, handled, -1, 128, nullptr, 0, &f);
+    if (rc != MSQ_OK) return rc;
+    ctx->dev_clean = true;  // untouched (not handled), or cleared by the fold
+    return MSQ_OK;
 }
 
 // ------------------------------------------------------------------------------------------ no-allocation door
