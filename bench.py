@@ -423,7 +423,7 @@ def main():
                 wl.name, shard_reads, W, wl.params.n_minors, 100.0 * wl.params.thr_minor / 4294967296.0,
                 len([s for s in wl.minor_sites if s[0] == 1]), wl.params.thr_sub / 4294967296.0,
                 "unset" if a.qualqv < 0 else a.qualqv) + (", rich QVs, SUBQV=42" if a.rich else ""), "mode": a.mode,
-                "window": {"known": "known at set-up; bounds recomputed per step in the prologue launch and checked",
+                "window": {"known": "known at set-up; bounds recomputed per step (inside the pileup kernel, msq_pileup_step; --unfused: in a launch of their own) and checked",
                            "device": "discovered on the device per step", "host": "host round trip per step"}[flow],
                 "exchange": ("one RCCL group per step (bounds MAX + counts SUM), library communicator" if flow == "known"
                              else "two RCCL all-reduces per step, library communicator") if multi else "none (one GPU)",

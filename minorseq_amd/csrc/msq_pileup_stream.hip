@@ -560,6 +560,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
 #ifdef MSQ_TRACE  // timing experiment: phase timestamps (100 MHz) of a few waves, printed at the end
     uint64_t tr_[8];
     int tr_n = 0;
+    uint32_t n_glob_ = 0, n_alt_ = 0;  // this lane's global / alt-counter atomics of the deviation path
     uint64_t ta_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tl_ = 0;  // per-batch segments, summed: chunks, phase 2, drain, zero rows, vmcnt(0), next
 #define MSQ_TR() (tr_[tr_n++] = wall_clock64())
 #define MSQ_TA0() (tl_ = wall_clock64())
@@ -859,6 +860,10 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             // two tight loops instead of one that carries all three cases: a deviating base (or, without an N
             // counter, an N) is one atomic on its nucleotide bin, a deviating codon one on its codon bin
             uint32_t bits = (nd & ~nd_alt) | nn;  // disjoint: nd lies in V, nn in X
+#ifdef MSQ_TRACE
+            n_glob_ += __popc(bits) + __popc(cd & ~cd_alt);
+            n_alt_ += __popc(nd_alt | cd_alt);
+#endif
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
@@ -1122,6 +1127,15 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     if (my_err) atomicOr(a.err, my_err);
 #ifdef MSQ_TRACE
     MSQ_TR();
+    for (int d = 32; d >= 1; d >>= 1) {
+        n_glob_ += __shfl_xor(n_glob_, d);
+        n_alt_ += __shfl_xor(n_alt_, d);
+    }
+    // every workgroup (its wave 0): when it ended relative to its start, what its drains cost, how many deviations
+    // went to global atomics and how many to the alt counters -- the kernel ends with its slowest workgroup
+    if (lane == 0 && wave == 0)
+        printf("wgt %3d total %6llu loop %6llu drain %6llu vmcnt0 %5llu glob %u alt %u\n", (int)blockIdx.x, (unsigned long long)(tr_[6] - tr_[0]),
+               (unsigned long long)(tr_[4] - tr_[3]), (unsigned long long)ta_[2], (unsigned long long)ta_[4], n_glob_, n_alt_);
     if (lane == 0 && (wave == 0 || wave == NWV - 1) && (blockIdx.x == 0 || blockIdx.x == 101 || blockIdx.x == gridDim.x - 1))
         printf("trace wg %3d wave %d: start %llu | init %4llu first-batch %4llu guide %4llu loop %5llu wait %4llu flush %4llu (x10 ns)\n", (int)blockIdx.x, wave,
                (unsigned long long)tr_[0], (unsigned long long)(tr_[1] - tr_[0]), (unsigned long long)(tr_[2] - tr_[1]),
