@@ -402,7 +402,9 @@ def main():
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # what the kernel really streams: 16 B of bit planes per 32-base group, 32 B per group for every QV plane a
         # threshold makes it read, 12 B of tables per read (the QV planes of an unmasked or baked set are never touched)
-        real_bytes = n_bases / 32 * (16 + 32 * (0 if baked else planes)) + 12.0 * shard_reads
+        # + 4 B per group of column index when the set carries one and the kernel variant uses it (no QV planes to read)
+        indexed = bool(run.dr.view.gcol) and (baked or planes == 0) and a.mode != "simple"
+        real_bytes = n_bases / 32 * (16 + 32 * (0 if baked else planes) + (4 if indexed else 0)) + 12.0 * shard_reads
         kernel_name = "pileup_simple_kernel" if a.mode == "simple" else "pileup_kernel"
         traffic = None if (a.rich or a.scaling == "strong" and world > 1) else load_traffic(kernel_name, wl.name, shard_reads, a.qualqv, baked)
         physical = (traffic or real_bytes) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -437,7 +439,7 @@ def main():
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes, "timed_steps": timed_steps,
                          # the physical side of the same launch: bytes really moved (PMC traffic when a pass of this
                          # exact configuration is committed, else the bytes the kernel streams) over the same time
-                         "streamed_bytes": real_bytes, "physical_gbs": physical, "frac_physical": physical / HBM_PEAK_GBS,
+                         "streamed_bytes": real_bytes, "column_index": indexed, "physical_gbs": physical, "frac_physical": physical / HBM_PEAK_GBS,
                          "limiter": "valu/latency" if physical < 0.5 * HBM_PEAK_GBS else "hbm",
                          # K1 + fold [+ exchange] + K2, SURVEY 8d's t_kernel(K1 + K2)
                          "path_ms": path_ms, "frac_path": (alg_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_ms else None},

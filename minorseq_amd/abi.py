@@ -43,6 +43,7 @@ class PackedReads(C.Structure):
         ("insqv", C.c_void_p),
         ("flags", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("gcol", C.c_void_p),
     ]
 
 
@@ -120,6 +121,7 @@ _SIGNATURES = {
     "msq_pileup_check": (C.c_int, [_P]),
     "msq_phase_codons": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "msq_pileup_begin": (C.c_int, [_P, C.POINTER(PackedReads), _P, _P, C.c_size_t]),
+    "msq_reads_index": (C.c_int, [_P, C.POINTER(PackedReads), _P]),
     "msq_pileup_step": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P]),
     "msq_timing_enable_strided": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "msq_timing_read_path": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),

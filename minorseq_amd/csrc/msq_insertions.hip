@@ -210,3 +210,53 @@ extern "C" int msq_insertion_records(msq_ctx* ctx, const msq_packed_reads* d_rea
     if (res[0] > capacity) return msq_fail(MSQ_ERR_RANGE, "msq_insertion_records: %llu records, capacity %llu", res[0], (unsigned long long)capacity);
     return MSQ_OK;
 }
+
+// ------------------------------------------------------------------------------------------ group column index
+// gcol[g] = reference column of group g's first column-consuming base | (read index & 7) << 29: what phase 1 of the
+// pileup otherwise works out per pass with a wave prefix sum and a walk over the read borders.  One wave per read,
+// lane i = group i of a 64-group block (any layout: only the op planes are looked at).
+namespace {
+__global__ __launch_bounds__(256) void index_groups_kernel(const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ group_off,
+                                                           const uint4* __restrict__ bop, uint64_t n_reads, uint32_t* __restrict__ gcol)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += n_waves) {
+        const uint64_t g_begin = group_off[r], g_end = group_off[r + 1];
+        uint32_t carry = (uint32_t)ref_start[r];
+        for (uint64_t blk = g_begin; blk < g_end; blk += 64) {
+            const uint64_t g = blk + (uint64_t)lane;
+            const int ncons = g < g_end ? __popc(~bop[g].w) : 0;
+            int incl = ncons;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d);
+                if (lane >= d) incl += up;
+            }
+            if (g < g_end) gcol[g] = ((carry + (uint32_t)(incl - ncons)) & 0x1fffffffu) | ((uint32_t)(r & 7u) << 29);
+            carry += (uint32_t)__shfl(incl, 63);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int msq_reads_index(msq_ctx* ctx, const msq_packed_reads* d_reads, uint32_t* d_gcol)
+{
+    if (!ctx || !d_reads || (d_reads->n_groups && !d_gcol)) return msq_fail(MSQ_ERR_ARG, "msq_reads_index: NULL argument");
+    if (d_reads->n_reads == 0) return MSQ_OK;
+    if (!d_reads->ref_start || !d_reads->group_off || !d_reads->bop) return msq_fail(MSQ_ERR_ARG, "msq_reads_index: NULL read arrays");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(index_groups_kernel, dim3(grid_for(ctx, d_reads->n_reads)), dim3(256), 0, ctx->stream, d_reads->ref_start,
+                       d_reads->group_off, (const uint4*)d_reads->bop, d_reads->n_reads, d_gcol);
+    MSQ_HIP(hipGetLastError());
+    return MSQ_OK;
+}
+int msq_packed_dev_index(msq_ctx* ctx, msq_packed_dev* d)
+{
+    if (d->view.n_groups == 0) return MSQ_OK;
+    hipError_t e = hipMalloc(&d->ptrs[8], d->view.n_groups * sizeof(uint32_t));
+    if (e != hipSuccess) return msq_fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "group column index: %s", hipGetErrorString(e));
+    int rc = msq_reads_index(ctx, &d->view, (uint32_t*)d->ptrs[8]);
+    if (rc != MSQ_OK) return rc;  // the owner frees ptrs[8] with the set
+    d->view.gcol = (const uint32_t*)d->ptrs[8];
+    return MSQ_OK;
+}

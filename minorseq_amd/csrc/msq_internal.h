@@ -59,7 +59,7 @@ struct msq_ctx {
 // Packed reads resident in HBM and owned by the library: the eight arrays of msq_packed_reads (ref_start, ref_end,
 // group_off, bop, qual, delqv, subqv, insqv; absent planes NULL) and the view over them.
 struct msq_packed_dev {
-    void* ptrs[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* ptrs[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [8]: the group column index
     msq_packed_reads view;
 };
 
@@ -81,6 +81,8 @@ int msq_fail(int code, const char* fmt, ...);
 
 int msq_scratch(msq_ctx* ctx, size_t bytes, void** out);
 int msq_noalloc_init(msq_ctx* ctx);
+// allocate and build the group column index of a library-owned device set (ptrs[8], view.gcol); async
+int msq_packed_dev_index(msq_ctx* ctx, msq_packed_dev* d);
 // The checks every entry point that streams packed reads shares: read arrays present, bit planes and QV planes
 // 16-byte aligned (the kernels load uint4), thresholds in -1..255 (qv_pass_mask's byte arithmetic).
 int msq_validate_reads(const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, const char* who);

@@ -161,7 +161,7 @@ extern "C" int msq_reads_upload(msq_ctx* ctx, const msq_packed_reads* h, msq_pac
         if (e == hipSuccess && bytes[k])
             e = hipMemcpyAsync(d->ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 9; ++j)
                 if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
             delete d;
             return msq_fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "msq_reads_upload: %s",
@@ -177,6 +177,14 @@ extern "C" int msq_reads_upload(msq_ctx* ctx, const msq_packed_reads* h, msq_pac
     d->view.delqv = (const uint8_t*)d->ptrs[5];
     d->view.subqv = (const uint8_t*)d->ptrs[6];
     d->view.insqv = (const uint8_t*)d->ptrs[7];
+    d->view.gcol = nullptr;
+    if (int rc = msq_packed_dev_index(ctx, d)) {  // the group column index, derived on the device
+        (void)hipStreamSynchronize(ctx->stream);
+        for (int j = 0; j < 9; ++j)
+            if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
+        delete d;
+        return rc;
+    }
     *out = d;
     return MSQ_OK;
 }
@@ -188,7 +196,7 @@ extern "C" int msq_packed_dev_free(msq_ctx* ctx, msq_packed_dev* p)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < 9; ++j)
         if (p->ptrs[j]) (void)hipFree(p->ptrs[j]);
     delete p;
     return MSQ_OK;
@@ -284,7 +292,7 @@ static uint64_t copy_or(uint64_t* dst, const msq_array_base* src, int64_t n)
 
 static void free_packed_dev(msq_packed_dev* d)
 {
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < 9; ++j)
         if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
     delete d;
 }
@@ -495,6 +503,12 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
         if ((thr.qual >= 0 && has_q) || (has_r && (thr.del >= 0 || thr.sub >= 0 || thr.ins >= 0))) v.flags |= MSQ_READS_QV_BAKED;
     }
     v.reserved = 0;
+    v.gcol = nullptr;
+    if (int rc2 = msq_packed_dev_index(ctx, d)) {
+        (void)hipStreamSynchronize(ctx->stream);
+        free_packed_dev(d);
+        return rc2;
+    }
     *out = d;
     return MSQ_OK;
 }

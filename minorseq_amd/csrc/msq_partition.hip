@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void slab_gather_kernel(const uint64_t* __rest
 void free_set(msq_packed_dev* d)
 {
     if (!d) return;
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < 9; ++j)
         if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
     delete d;
 }
@@ -173,6 +173,7 @@ extern "C" int msq_reads_partition(msq_ctx* ctx, const msq_packed_reads* d_reads
             if (!d) return fail(MSQ_ERR_NOMEM, "out of memory", hipSuccess);
             d->view = *d_reads;
             d->view.n_reads = d->view.n_groups = 0;
+            d->view.gcol = nullptr;
             p->sets.push_back(d);
         }
         *out = p;
@@ -248,6 +249,8 @@ extern "C" int msq_reads_partition(msq_ctx* ctx, const msq_packed_reads* d_reads
         v.insqv = (const uint8_t*)d->ptrs[7];
         v.flags = d_reads->flags;
         v.reserved = 0;
+        v.gcol = nullptr;
+        if (msq_packed_dev_index(ctx, d) != MSQ_OK) return fail(MSQ_ERR_HIP, "group column index", hipGetLastError());  // a sub-read is a read
     }
     e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(MSQ_ERR_HIP, "synchronise", e);

@@ -36,6 +36,9 @@
 // MSQ_EXP: compile-time timing experiments only (make EXTRA=-DMSQ_EXP=n); any non-zero value gives WRONG counts.
 // bit 0 skip the LDS ORs of phase 1, bit 1 skip phase 2 + drain, bit 2 skip the squeeze, bit 3 skip the drain,
 // bit 4 skip zero_rows, bit 5 skip the counter transposition of the flush.  The shipped library is always built with 0.
+#ifndef MSQ_NO_IDX
+#define MSQ_NO_IDX 0  // experiment builds: ignore the sets' column index
+#endif
 #ifndef MSQ_NO_ALT  // experiment builds: every deviation from the guide pays a global atomic, as before the alt haplotype
 #define MSQ_NO_ALT 0
 #endif
@@ -94,6 +97,7 @@ struct StreamArgs {
     int32_t ph_n, ph_total; // positions of this launch, of the caller's list (the key row length)
     uint16_t* ph_keys;      // [n_reads][ph_total]
     // msq_pileup_step: the shard's bounds come out of this launch too (NULL otherwise)
+    const uint32_t* gcol;   // [n_groups] (kernels with IDX): first reference column of the group | (read index & 7) << 29
     const int32_t* ref_end;
     uint32_t* bounds_acc;   // {max of ~begin, max of end, workgroups done}, order-encoded; left at zero
     int32_t* bounds_out;    // {-begin0, end0}
@@ -352,6 +356,7 @@ __device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl
 template <int NP>
 struct Slot {  // one chunk (64 groups) in flight
     uint4 w;
+    uint32_t m;  // IDX kernels: the group's column index word
     uint4 qa[NP ? NP : 1], qb[NP ? NP : 1];
 };
 
@@ -488,6 +493,7 @@ struct ChunkProducer {
 // where read i begins (lanes 1..7; every other lane holds ~0), rqv = its start column.  The decode walks the
 // read borders with a scalar cursor (bi, bnext) and v_readlane.  The next batch's raw entries come through two
 // plain vector loads issued when the current batch's chunks are done.
+template <bool IDX>
 struct BatchConsumer {
     const uint32_t* go32;  // group_off viewed as dwords (a batch spans < 2^32 groups: low dwords suffice)
     const int32_t* rs;
@@ -507,7 +513,7 @@ struct BatchConsumer {
     {
         const uint64_t r0 = read_lo + (uint64_t)min(bb, n_batches - 1u) * kRows;
         n_go = go32[2 * min(r0 + (uint64_t)min(lane, kRows), read_hi)];
-        n_rs = rs[min(r0 + (uint64_t)min(lane, kRows - 1), read_hi - 1)];
+        if (!IDX) n_rs = rs[min(r0 + (uint64_t)min(lane, kRows - 1), read_hi - 1)];
     }
     __device__ __forceinline__ void begin(const BatchDraw& bd, int lane)  // make the prefetched batch current
     {
@@ -516,11 +522,13 @@ struct BatchConsumer {
         if (live) {
             const uint32_t rel = n_go - (uint32_t)__builtin_amdgcn_readlane((int)n_go, 0);
             rel8 = (uint32_t)__builtin_amdgcn_readlane((int)rel, kRows);
+            if (!IDX) {
             bqv = (lane >= 1 && lane < kRows) ? rel : 0xffffffffu;
             rqv = n_rs - win;  // MSA.cpp:148: pos = ReferenceStart - beginPos
             cb_cur = __builtin_amdgcn_readlane(rqv, 0);
             bi = 1;
             bnext = (uint32_t)__builtin_amdgcn_readlane((int)bqv, 1);
+            }
             nchunks = uni(max(1u, (rel8 + 63u) >> 6));
             c = 0;
             rowoff_cur = 0;
@@ -550,7 +558,8 @@ struct BatchConsumer {
 // (MSARow::CodonAt at the requested positions, src/AminoAcidCaller.cpp:149-160) instead of the counting.
 // MANY_N: Ns are common (a QV mask, applied here or baked into the planes at pack time): they get a counter of
 // their own instead of going down the deviation path.
-template <int NP, int PASSES, bool PHASE, bool MANY_N = (NP != 0)>
+// IDX: the set carries the group column index (msq_reads_index), see phase 1.
+template <int NP, int PASSES, bool PHASE, bool MANY_N = (NP != 0), bool IDX = false>
 __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(StreamArgs a)
 {
     constexpr int NS = slots_of(NP, PASSES);
@@ -652,6 +661,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     auto issue = [&](Slot<NP>& s) {
         const uint32_t soff = uni(pr.c * 1024u);
         s.w = buffer_load16(__builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)pr.cur_base, 0, (int)pr.cur_bytes, 0x00020000), lane16, soff);
+        if (IDX) s.m = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pr.rsrc(a.gcol, 2), (int)lane * 4, (int)(soff >> 2), 0);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             s.qa[k] = buffer_load16(pr.rsrc(a.qv[k], 5), lane32, 2u * soff);
@@ -661,7 +671,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     };
 
     // ---- phase 1 for one chunk: read space -> column-space planes in LDS (MSAByRow::AddRead, MSA.cpp:144-186)
-    BatchConsumer cs;
+    BatchConsumer<IDX> cs;
     auto decode = [&](const Slot<NP>& s) {
         const uint32_t g0 = 64u * cs.c;
         const uint32_t nvalid = cs.rel8 > g0 ? min(cs.rel8 - g0, 64u) : 0u;
@@ -680,10 +690,19 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         uint32_t b1 = w.y & pv;
         const int n = __popc(cons);
         if (!(MSQ_EXP & 4) && !a.normalized) squeeze4(cons, pv, px, b0, b1);  // wave-uniform
+        uint32_t rowoffv;
+        int c0;
+        if constexpr (IDX) {
+            // the set carries a column index (msq_reads_index): a group knows its first column and its read's row in the
+            // batch -- no prefix sum over the wave, no walk over the read borders
+            rowoffv = (((s.m >> 29) - ((uint32_t)a.read_lo & 7u)) & 7u) * (uint32_t)ROWB;
+            c0 = (int)(s.m & 0x1fffffffu) - win_begin0;
+            cs.c = uni(cs.c + 1u);
+        } else {
         const int incl = wave_inclusive_scan(n);
         const int excl = incl - n;
         // read borders inside this chunk: lanes from the border on belong to the next read / row
-        uint32_t rowoffv = cs.rowoff_cur;
+        rowoffv = cs.rowoff_cur;
         int32_t cbv = cs.cb_cur;
         while (cs.bnext < g0 + 64u) {  // wave-uniform
             const uint32_t sl = cs.bnext - g0;
@@ -696,9 +715,10 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             cs.bi = uni(cs.bi + 1u);
             cs.bnext = uni((uint32_t)__builtin_amdgcn_readlane((int)cs.bqv, (int)cs.bi));  // lane 8 holds ~0: no border left
         }
-        const int c0 = cbv + (int32_t)cs.C + excl;  // column of this lane's first base
+        c0 = cbv + (int32_t)cs.C + excl;  // column of this lane's first base
         cs.C = uni(cs.C + (uint32_t)__builtin_amdgcn_readlane(incl, 63));
         cs.c = uni(cs.c + 1u);
+        }
         if (n) {
             if (c0 < 0 || c0 + n > W) {
                 my_err |= DEVERR_WINDOW;  // assert(pos >= 0) / write past the row, MSA.cpp:149
@@ -1255,8 +1275,12 @@ __global__ __launch_bounds__(kFoldCols* kFoldSubs) void fold_partials_kernel(con
 
 typedef void (*pileup_kernel_fn)(StreamArgs);
 
-pileup_kernel_fn pick_kernel(int np, int passes, bool many_n)
+pileup_kernel_fn pick_kernel(int np, int passes, bool many_n, bool idx)
 {
+    if (np == 0 && idx) {  // the kernels a run takes (thresholds baked or unset) come with and without the column index
+        if (many_n) return passes == 1 ? pileup_kernel<0, 1, false, true, true> : pileup_kernel<0, 2, false, true, true>;
+        return passes == 1 ? pileup_kernel<0, 1, false, false, true> : pileup_kernel<0, 2, false, false, true>;
+    }
     if (np == 0 && many_n) return passes == 1 ? pileup_kernel<0, 1, false, true> : pileup_kernel<0, 2, false, true>;
     if (passes == 1) {
         return np == 0   ? pileup_kernel<0, 1, false>
@@ -1266,8 +1290,9 @@ pileup_kernel_fn pick_kernel(int np, int passes, bool many_n)
     }
     return np == 0 ? pileup_kernel<0, 2, false> : np == 1 ? pileup_kernel<1, 2, false> : np == 2 ? pileup_kernel<2, 2, false> : pileup_kernel<4, 2, false>;
 }
-pileup_kernel_fn pick_phase_kernel(int np)
+pileup_kernel_fn pick_phase_kernel(int np, bool idx)
 {
+    if (np == 0 && idx) return pileup_kernel<0, 1, true, false, true>;
     return np == 0 ? pileup_kernel<0, 1, true> : np == 1 ? pileup_kernel<1, 1, true> : np == 2 ? pileup_kernel<2, 1, true> : pileup_kernel<4, 1, true>;
 }
 
@@ -1351,6 +1376,8 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     a.ph_pos = a.ph_idx = nullptr;
     a.ph_n = a.ph_total = 0;
     a.ph_keys = nullptr;
+    a.gcol = R.gcol;
+    const bool idx = R.gcol != nullptr && np_kernel == 0 && !MSQ_NO_IDX;  // the QV-plane kernels (a fallback) keep the prefix sum
     a.ref_end = nullptr;
     a.bounds_acc = nullptr;
     a.bounds_out = nullptr;
@@ -1395,7 +1422,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
         if (nwv < 1) return msq_fail(MSQ_ERR_ARG, "msq_pileup: no LDS for a %d-word slab", G);
         // the pileup's counters hold 1023 reads per wave and launch; the gather has no such limit
         const uint64_t reads_per_launch = phase ? R.n_reads : (uint64_t)ctx->n_cu * nwv * kMaxBatchesPerWave * kRows;
-        pileup_kernel_fn kern = phase ? pick_phase_kernel(np_kernel) : pick_kernel(np_kernel, passes, many_n);
+        pileup_kernel_fn kern = phase ? pick_phase_kernel(np_kernel, idx) : pick_kernel(np_kernel, passes, many_n, idx);
         if (fused && R.n_reads > reads_per_launch) return MSQ_OK;  // more than one launch: not for the fused step
         if (phase) {
             void* s = nullptr;

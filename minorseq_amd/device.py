@@ -80,10 +80,11 @@ def pack_host(reads):
     return out
 
 
-def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases=0, plain=False, thr=None):
+def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases=0, plain=False, thr=None, keep=False):
     """msq_pack_reads_device on unpacked reads (the dict pack_host takes) -> the packed arrays copied back from HBM,
     in pack_host()'s layout.  has_qual / has_rich: per-base presence bytes (default: present wherever the dict
-    holds the QV array).  thr: msq_pack_reads_device_baked with these thresholds instead."""
+    holds the QV array).  thr: msq_pack_reads_device_baked with these thresholds instead.  keep: return the
+    library-owned device set (LibReads) instead."""
     L = abi.lib()
     n = int(reads["n_reads"])
     off = np.asarray(reads["base_off"], dtype=np.int64)
@@ -108,6 +109,8 @@ def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases
     else:
         abi.check(L.msq_pack_reads_device_baked(ctx.h, n, abi.ptr(reads["ref_start"]), abi.ptr(reads["ref_end"]), abi.ptr(ptrs),
                                                 abi.ptr(lens), abi.MSQ_PACK_PLAIN if plain else 0, threads, chunk_bases, thr, C.byref(h)))
+    if keep:  # the library-owned set itself (LibReads), not a copy of its arrays
+        return LibReads(ctx, h)
     try:
         v = L.msq_packed_dev_view(h).contents
         g = int(v.n_groups)
@@ -122,7 +125,8 @@ def pack_device(ctx, reads, has_qual=None, has_rich=None, threads=0, chunk_bases
         out = {"n_reads": int(v.n_reads), "n_groups": g, "ref_start": back(v.ref_start, np.int32, n), "ref_end": back(v.ref_end, np.int32, n),
                "group_off": back(v.group_off, np.uint64, n + 1), "bop": back(v.bop, np.uint32, g * 4),
                "qual": back(v.qual, np.uint8, g * 32), "delqv": back(v.delqv, np.uint8, g * 32),
-               "subqv": back(v.subqv, np.uint8, g * 32), "insqv": back(v.insqv, np.uint8, g * 32), "flags": int(v.flags)}
+               "subqv": back(v.subqv, np.uint8, g * 32), "insqv": back(v.insqv, np.uint8, g * 32), "flags": int(v.flags),
+               "gcol": back(v.gcol, np.uint32, g)}
     finally:
         L.msq_packed_dev_free(ctx.h, h)
     return out
@@ -136,7 +140,17 @@ class DeviceReads:
     def __init__(self, n_reads, n_groups, tensors, flags=0):
         self.n_reads, self.n_groups, self.t, self.flags = int(n_reads), int(n_groups), tensors, int(flags)
         self.view = abi.PackedReads(self.n_reads, self.n_groups,
-                                    *[abi.ptr(tensors.get(f)) for f in self.FIELDS], self.flags, 0)
+                                    *[abi.ptr(tensors.get(f)) for f in self.FIELDS], self.flags, 0, abi.ptr(tensors.get("gcol")))
+
+    def index(self, ctx):
+        """Build the group column index (msq_reads_index) and hang it into the view: the pileup / phasing kernels then
+        skip phase 1's prefix sum.  Without it (plain `upload`) the same kernels take the sum-and-walk path."""
+        if self.n_groups and self.t.get("gcol") is None:
+            g = torch.zeros(self.n_groups, dtype=torch.int32, device=self.t["bop"].device)
+            abi.check(abi.lib().msq_reads_index(ctx.h, self.view, g.data_ptr()))
+            self.t["gcol"] = g
+            self.view.gcol = g.data_ptr()
+        return self
 
     def n_bytes(self):
         return sum(t.numel() * t.element_size() for t in self.t.values() if t is not None)
@@ -153,7 +167,7 @@ class LibReads:
 
     def n_bytes(self):
         planes = sum(1 for f in ("qual", "delqv", "subqv", "insqv") if getattr(self.view, f))
-        return self.n_reads * 8 + (self.n_reads + 1) * 8 + self.n_groups * (16 + 32 * planes)
+        return self.n_reads * 8 + (self.n_reads + 1) * 8 + self.n_groups * (16 + 32 * planes + (4 if self.view.gcol else 0))
 
     def download(self):
         """-> dict of numpy arrays in the pack_host() layout."""
@@ -190,7 +204,8 @@ def bake_qv(ctx, dr, thr):
     return LibReads(ctx, h)
 
 
-def upload(packed, device=0):
+def upload(packed, device=0, ctx=None):
+    """Host arrays of pack_host() -> DeviceReads; with a context the set also gets its group column index."""
     dev = torch.device("cuda", device)
     t = {}
     for f in DeviceReads.FIELDS:
@@ -205,7 +220,8 @@ def upload(packed, device=0):
         if a.size == 0:
             a = np.zeros(4, dtype=a.dtype)
         t[f] = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    return DeviceReads(packed["n_reads"], packed["n_groups"], t, packed.get("flags", 0))
+    dr = DeviceReads(packed["n_reads"], packed["n_groups"], t, packed.get("flags", 0))
+    return dr.index(ctx) if ctx is not None else dr
 
 
 def download(dr):
@@ -252,6 +268,7 @@ def synth_device(ctx, wl, first=0, n=None):
     }
     dr = DeviceReads(n, g, t, abi.MSQ_READS_NORMALIZED)  # the generator writes normalized groups
     abi.check(L.msq_synth_dev_fill(ctx.h, wl.params, clones.data_ptr(), first, dr.view))
+    dr.index(ctx)
     ctx.sync()
     return dr
 
