@@ -103,10 +103,10 @@ typedef struct msq_packed_reads {
 #define MSQ_READS_INS_EXOTIC 16u /* some inserted ('I') base is not ACGT: it was packed as 'A'; insertion strings taken from
                                    the packed planes differ from the reference's there (see msq_insertion.read / first_base) */
 
-/* The group column index of a packed set in HBM: gcol[g] = reference column of group g's first column-consuming
- * base | (index of its read & 7) << 29 -- `pos` of MSAByRow::AddRead (src/MSA.cpp:148,172-176) at the group's first
+/* The group column index of a packed set in HBM: gcol[g] = (reference column of group g's first column-consuming
+ * base + 1) | (index of its read & 7) << 29 -- `pos` of MSAByRow::AddRead (src/MSA.cpp:148,172-176) at the group's first
  * base, which every pass over the set otherwise recomputes with a prefix sum over the groups and a walk over the
- * read borders.  Derived data, 4 bytes per 32 bases, any group layout; reference columns < 2^29.  A set whose view
+ * read borders.  Derived data, 4 bytes per 32 bases, any group layout; reference columns < 2^29 - 1; a valid word is never 0.  A set whose view
  * carries it (`gcol` != NULL) is piled up and phased ~6 % faster; a view with gcol == NULL works as before.  Every
  * device set the library makes (msq_reads_upload, msq_pack_reads_device*, msq_reads_bake_qv, msq_reads_partition)
  * carries one; for a caller-made view: d_gcol = n_groups u32 of device memory, then view.gcol = d_gcol.  The index

@@ -212,7 +212,7 @@ extern "C" int msq_insertion_records(msq_ctx* ctx, const msq_packed_reads* d_rea
 }
 
 // ------------------------------------------------------------------------------------------ group column index
-// gcol[g] = reference column of group g's first column-consuming base | (read index & 7) << 29: what phase 1 of the
+// gcol[g] = (reference column of group g's first column-consuming base + 1) | (read index & 7) << 29: what phase 1 of the
 // pileup otherwise works out per pass with a wave prefix sum and a walk over the read borders.  One wave per read,
 // lane i = group i of a 64-group block (any layout: only the op planes are looked at).
 namespace {
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void index_groups_kernel(const int32_t* __rest
                 const int up = __shfl_up(incl, d);
                 if (lane >= d) incl += up;
             }
-            if (g < g_end) gcol[g] = ((carry + (uint32_t)(incl - ncons)) & 0x1fffffffu) | ((uint32_t)(r & 7u) << 29);
+            // column + 1: a valid word is never 0 (what a load past the end of a batch returns)
+            if (g < g_end) gcol[g] = ((carry + (uint32_t)(incl - ncons) + 1u) & 0x1fffffffu) | ((uint32_t)(r & 7u) << 29);
             carry += (uint32_t)__shfl(incl, 63);
         }
     }

@@ -430,6 +430,7 @@ struct ChunkProducer {
     uint64_t bop_base;
     uint64_t cur_base;  // the bit planes' buffer resource over the current batch: base address and bytes
     uint32_t cur_bytes;
+    uint64_t idx_base, cur_ibase;  // the same for the group column index (4 bytes per group), when the set has one
 
     // buffer resource over the current batch's groups of one plane (2^shift bytes per group)
     template <typename T>
@@ -443,6 +444,7 @@ struct ChunkProducer {
         const uint32_t nch = max(1u, (ng + 63u) >> 6);
         nslots = uni((nch + ns - 1u) / ns * ns);
         cur_base = uni64(bop_base + (B0 << 4));
+        cur_ibase = uni64(idx_base + (B0 << 2));
         cur_bytes = uni(live ? ng << 4 : 0u);  // zero records for a wave that has run out of batches: every load reads zeros
     }
     __device__ __forceinline__ void fetch(uint32_t bb, uint64_t& o0, uint32_t& n, uint32_t& alive)
@@ -457,11 +459,12 @@ struct ChunkProducer {
             n = uni((uint32_t)(uni64(go[r1]) - o0));
         }
     }
-    __device__ __forceinline__ void init(const BatchDraw& bd, const uint64_t* group_off, const void* bop, uint64_t lo, uint64_t hi,
-                                         uint32_t nb, uint32_t ns)
+    __device__ __forceinline__ void init(const BatchDraw& bd, const uint64_t* group_off, const void* bop, const void* gcol, uint64_t lo,
+                                         uint64_t hi, uint32_t nb, uint32_t ns)
     {
         go = (const_u64_ptr)(uintptr_t)group_off;
         bop_base = (uint64_t)(uintptr_t)bop;
+        idx_base = (uint64_t)(uintptr_t)gcol;
         read_lo = lo; read_hi = hi; n_batches = nb;
         P = 0;
         c = 0;
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
 
     // ---- producer: one unconditional chunk load per call (clamped addresses, no predicate around the loads)
     ChunkProducer pr;
-    pr.init(bd, a.group_off, a.bop, a.read_lo, a.read_hi, (uint32_t)a.n_batches, NS);
+    pr.init(bd, a.group_off, a.bop, a.gcol, a.read_lo, a.read_hi, (uint32_t)a.n_batches, NS);
     // The chunk loads are buffer loads: the resource covers exactly the producer's current batch (base = its first
     // group, num_records = its bytes; zero records for a wave that has run out of batches), the lane's byte offset is
     // a constant VGPR and the chunk's offset rides in the scalar operand -- no address arithmetic per load, and a
@@ -661,7 +664,10 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     auto issue = [&](Slot<NP>& s) {
         const uint32_t soff = uni(pr.c * 1024u);
         s.w = buffer_load16(__builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)pr.cur_base, 0, (int)pr.cur_bytes, 0x00020000), lane16, soff);
-        if (IDX) s.m = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pr.rsrc(a.gcol, 2), (int)lane * 4, (int)(soff >> 2), 0);
+        if (IDX)
+            s.m = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)pr.cur_ibase, 0, (int)(pr.cur_bytes >> 2), 0x00020000), (int)lane * 4,
+                (int)(soff >> 2), 0);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
             s.qa[k] = buffer_load16(pr.rsrc(a.qv[k], 5), lane32, 2u * soff);
@@ -679,7 +685,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         uint32_t pass = ~0u;  // ArrayBase::MeetQVThresholds, ArrayRead.inl:67-87
 #pragma unroll
         for (int k = 0; k < NP; ++k) pass &= qv_pass_mask(s.qa[k], s.qb[k], a.thr[k]);
-        const uint32_t cons = (uint32_t)lane < nvalid ? ~w.w : 0u;  // ops 0, 1 consume a column
+        // ops 0, 1 consume a column; a lane past the batch's last group loaded zeros (the buffer's range check): with an
+        // index its word says so (valid words are never 0), without one the lane number does
+        const uint32_t cons = (IDX ? s.m != 0u : (uint32_t)lane < nvalid) ? ~w.w : 0u;
         const uint32_t is_m = cons & ~w.z;          // op 0: '=' / 'X'
         const uint32_t op1 = cons & w.z;            // op 1: '-', literal N, exotic
         exotic |= op1 & w.y;                        // exotic codes are the simple kernel's job (checked at the end)
@@ -695,8 +703,8 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         if constexpr (IDX) {
             // the set carries a column index (msq_reads_index): a group knows its first column and its read's row in the
             // batch -- no prefix sum over the wave, no walk over the read borders
-            rowoffv = (((s.m >> 29) - ((uint32_t)a.read_lo & 7u)) & 7u) * (uint32_t)ROWB;
-            c0 = (int)(s.m & 0x1fffffffu) - win_begin0;
+            rowoffv = __umul24(((s.m >> 29) - ((uint32_t)a.read_lo & 7u)) & 7u, (uint32_t)ROWB);
+            c0 = (int)(s.m & 0x1fffffffu) - 1 - win_begin0;
             cs.c = uni(cs.c + 1u);
         } else {
         const int incl = wave_inclusive_scan(n);
@@ -726,14 +734,19 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
                 // the lane's words at bit offset sh of slab word cs0 >> 5 (row word + 1; -1 = the leading margin):
                 // low part, and the spill into the next word
                 const int cs0 = c0 - slab0;
-                const int sh = cs0 & 31, rs = 31 - sh;
-                uint64_t* p = reinterpret_cast<uint64_t*>(wrow + rowoffv + ((cs0 >> 5) + 1) * 4);
-                const uint64_t lo_vx = (uint64_t)(pv << sh) | ((uint64_t)(px << sh) << 32);
-                const uint64_t lo_b = (uint64_t)(b0 << sh) | ((uint64_t)(b1 << sh) << 32);
-                const uint64_t hi_vx = (uint64_t)((pv >> 1) >> rs) | ((uint64_t)((px >> 1) >> rs) << 32);
-                const uint64_t hi_b = (uint64_t)((b0 >> 1) >> rs) | ((uint64_t)((b1 >> 1) >> rs) << 32);
+                // byte address of row word (cs0 >> 5) + 1: ((cs0 >> 5) + 1) * 16 = ((cs0 >> 1) & ~15) + 16
+                uint64_t* p = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(wrow) + (rowoffv << 2) + (((cs0 >> 1) & ~15) + 16));
+                // a plane rotated left by the bit offset holds its low part above the offset and its spill below:
+                // one funnel shift and two masks per plane instead of three shifts
+                const uint32_t keep_lo = 0xffffffffu << (cs0 & 31);
+                auto rot = [&](uint32_t x) { return __builtin_amdgcn_alignbit(x, x, (uint32_t)(-cs0)); };  // the shift takes -cs0 mod 32
+                const uint32_t rv = rot(pv), rx = rot(px), r0 = rot(b0), r1 = rot(b1);
+                const uint64_t lo_vx = (uint64_t)(rv & keep_lo) | ((uint64_t)(rx & keep_lo) << 32);
+                const uint64_t lo_b = (uint64_t)(r0 & keep_lo) | ((uint64_t)(r1 & keep_lo) << 32);
+                const uint64_t hi_vx = (uint64_t)(rv & ~keep_lo) | ((uint64_t)(rx & ~keep_lo) << 32);
+                const uint64_t hi_b = (uint64_t)(r0 & ~keep_lo) | ((uint64_t)(r1 & ~keep_lo) << 32);
                 if (MSQ_EXP & 1) {  // timing experiment: keep the operands alive, leave out the LDS atomics
-                    if (((lo_vx ^ lo_b ^ hi_vx ^ hi_b) + (uint64_t)(rowoffv + (cs0 >> 5) * 4)) == 0x123456789abcdef1ull) my_err |= DEVERR_RANGE;
+                    if (((lo_vx ^ lo_b ^ hi_vx ^ hi_b) + (uint64_t)(uintptr_t)p) == 0x123456789abcdef1ull) my_err |= DEVERR_RANGE;
                 } else {
                     lds_or64(p, lo_vx);
                     lds_or64(p + 1, lo_b);

@@ -29,7 +29,7 @@ def host_index(p):
         g0, g1 = int(p["group_off"][r]), int(p["group_off"][r + 1])
         col = int(p["ref_start"][r])
         for g in range(g0, g1):
-            out[g] = (col & 0x1fffffff) | ((r & 7) << 29)
+            out[g] = ((col + 1) & 0x1fffffff) | ((r & 7) << 29)
             col += int(ncons[g])
     return out
 
