@@ -65,6 +65,9 @@ def parse():
                     "<= 4096); narrower than the window: partition even a window that fits one slab")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: create the library's RCCL communicator and "
                     "issue the step's collectives even with one rank")
+    ap.add_argument("--exchange", default="lib", choices=["lib", "torch"], help="N > 1: the library's RCCL communicator "
+                    "(msq_comm_*) or, for comparison, torch.distributed's RCCL group (also the fallback when the "
+                    "library communicator cannot be made; the line's config.exchange says which ran)")
     ap.add_argument("--time-every", type=int, default=4, help="HIP events around the pileup kernel in every n-th step")
     ap.add_argument("--verify", action="store_true", help="after the timed loop: the count matrices of the last step "
                     "against the independent simple kernel's (bit for bit)")
@@ -325,9 +328,30 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        ex = sharding.LibExchange(ctx, rank, world, sharding.torch_bootstrap)
+        ex_note = None
+        try:
+            if a.exchange == "torch":
+                raise RuntimeError("--exchange torch")
+            ex, err = sharding.LibExchange(ctx, rank, world, sharding.torch_bootstrap), ""
+        except Exception as e:  # noqa: BLE001 -- reported in the JSON line
+            ex, err = None, "%s: %s" % (type(e).__name__, e)
+        # every rank must take the same road: one that could not make its communicator sends all of them to
+        # torch.distributed's RCCL (same collectives, same stream), and the line says so
+        bad = [None] * world
+        dist.all_gather_object(bad, err)
+        if any(bad):
+            if ex is not None:
+                ex.close()
+            grp = dist.new_group(backend="nccl")
+
+            class _CudaTorchExchange(sharding.TorchExchange):
+                def allreduce_bounds(self, begin0, end0):
+                    return sharding.TorchExchange.allreduce_bounds(self, begin0, end0, device=torch.device("cuda", local))
+            ex = _CudaTorchExchange(grp)
+            ex_note = "torch.distributed RCCL group (the library communicator failed: %s)" % next(b for b in bad if b)
+            print("bench: " + ex_note, file=sys.stderr)
     else:
-        ex = sharding.NoExchange()
+        ex, ex_note = sharding.NoExchange(), None
 
     wl = synth.workload(a.workload, **workload_kwargs(a))
     reads = a.reads or wl.n_reads
@@ -427,8 +451,8 @@ def main():
                 "unset" if a.qualqv < 0 else a.qualqv) + (", rich QVs, SUBQV=42" if a.rich else ""), "mode": a.mode,
                 "window": {"known": "known at set-up; bounds recomputed per step (inside the pileup kernel, msq_pileup_step; --unfused: in a launch of their own) and checked",
                            "device": "discovered on the device per step", "host": "host round trip per step"}[flow],
-                "exchange": ("one RCCL group per step (bounds MAX + counts SUM), library communicator" if flow == "known"
-                             else "two RCCL all-reduces per step, library communicator") if multi else "none (one GPU)",
+                "exchange": (ex_note or ("one RCCL group per step (bounds MAX + counts SUM), library communicator" if flow == "known"
+                                          else "two RCCL all-reduces per step, library communicator")) if multi else "none (one GPU)",
                 "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 127) // 128),
                 "read_layout": "column-slab partition (built at set-up)" if n_slabs else "one read set",
                 "qv_thresholds": "unset" if a.qualqv < 0 and not a.rich else "applied at pack time (baked; the bake pass is set-up, not timed)" if baked else "applied in every pass",

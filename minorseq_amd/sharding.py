@@ -66,7 +66,11 @@ class LibExchange:
 
 
 class TorchExchange:
-    """The same exchange over torch.distributed tensors (CPU rehearsal with gloo; a no-op outside a process group)."""
+    """The same exchange over torch.distributed tensors (CPU rehearsal with gloo; a no-op outside a process group).
+    group: the process group to use (default: the world group)."""
+
+    def __init__(self, group=None):
+        self.group = group
 
     @staticmethod
     def _on():
@@ -75,13 +79,13 @@ class TorchExchange:
     def allreduce_bounds_device(self, bounds):
         if self._on():
             assert bounds.dtype == torch.int32 and bounds.numel() == 2
-            dist.all_reduce(bounds, op=dist.ReduceOp.MAX)
+            dist.all_reduce(bounds, op=dist.ReduceOp.MAX, group=self.group)
         return bounds
 
     def allreduce_counts(self, counts):
         if self._on():
             assert counts.dtype == torch.int32 and counts.is_contiguous()
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)  # int32 view: two's-complement sums are the u32 sums
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)  # int32 view: two's-complement sums are the u32 sums
         return counts
 
     def allreduce_step(self, bounds, counts):
@@ -92,7 +96,7 @@ class TorchExchange:
         if not self._on():
             return int(begin0), int(end0)
         t = torch.tensor([-int(begin0), int(end0)], dtype=torch.int64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         lo, hi = t.tolist()
         return -int(lo), int(hi)
 
