@@ -124,7 +124,7 @@ extern "C" int msq_phase_cluster(msq_ctx* ctx, const uint16_t* d_keys, uint64_t 
     *n_clusters = 0;
     if (n_pos < 0) return msq_fail(MSQ_ERR_ARG, "msq_phase_cluster: negative row length");
     if (n_reads == 0) return MSQ_OK;
-    if (n_reads > 0xfffffff0ull) return msq_fail(MSQ_ERR_ARG, "msq_phase_cluster: too many reads");
+    if (n_reads > 0x7fffffffull) return msq_fail(MSQ_ERR_ARG, "msq_phase_cluster: too many reads (hipCUB counts in int)");
     if ((n_pos > 0 && !d_keys) || !d_cluster_of || !d_first_read || !d_count) return msq_fail(MSQ_ERR_ARG, "msq_phase_cluster: NULL device buffer");
     MSQ_HIP(hipSetDevice(ctx->device));
     const uint64_t n = n_reads;

@@ -233,7 +233,9 @@ __global__ __launch_bounds__(256) void index_groups_kernel(const int32_t* __rest
                 if (lane >= d) incl += up;
             }
             // column + 1: a valid word is never 0 (what a load past the end of a batch returns)
-            if (g < g_end) gcol[g] = ((carry + (uint32_t)(incl - ncons) + 1u) & 0x1fffffffu) | ((uint32_t)(r & 7u) << 29);
+            // columns the 29 bits cannot hold saturate: such a group lies outside every window the kernels take an index
+            // for (stream_launch), and is reported there like any base outside the window
+            if (g < g_end) gcol[g] = min(carry + (uint32_t)(incl - ncons) + 1u, 0x1fffffffu) | ((uint32_t)(r & 7u) << 29);
             carry += (uint32_t)__shfl(incl, 63);
         }
     }

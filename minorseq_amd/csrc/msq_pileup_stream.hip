@@ -1390,7 +1390,8 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     a.ph_n = a.ph_total = 0;
     a.ph_keys = nullptr;
     a.gcol = R.gcol;
-    const bool idx = R.gcol != nullptr && np_kernel == 0 && !MSQ_NO_IDX;  // the QV-plane kernels (a fallback) keep the prefix sum
+    // the QV-plane kernels (a fallback) keep the prefix sum; so do windows the index's 29 column bits cannot address
+    const bool idx = R.gcol != nullptr && np_kernel == 0 && !MSQ_NO_IDX && win_begin0 >= 0 && (int64_t)win_begin0 + W < 0x1fffff00;
     a.ref_end = nullptr;
     a.bounds_acc = nullptr;
     a.bounds_out = nullptr;

@@ -121,3 +121,17 @@ def test_library_sets_carry_an_index_and_qv_kernels_ignore_it(ctx):
     part.close()
     baked.close()
     lib_set.close()
+
+
+def test_columns_beyond_the_index_range(ctx):
+    """A read the 29 column bits cannot address is outside every window an indexed kernel takes: it raises the same
+    deferred window error as without the index, and a window out there is piled up by the sum-and-walk path."""
+    reads = cases.make_reads([(10, "=" * 40, "ACGT" * 10), ((1 << 29) + 10, "=" * 40, "ACGT" * 10)])
+    packed = device.pack_host(reads)
+    for with_ctx in (None, ctx):
+        dr = device.upload(packed, ctx.device, ctx=with_ctx)
+        nuc, codon = device.alloc_counts(ctx, 64)
+        abi.check(abi.lib().msq_pileup(ctx.h, dr.view, NONE, 0, 64, nuc.data_ptr(), codon.data_ptr(), abi.MSQ_PILEUP_STREAM))
+        assert abi.lib().msq_pileup_check(ctx.h) == abi.MSQ_ERR_WINDOW
+    far = cases.make_reads([((1 << 29) + 10, "=" * 40, "ACGT" * 10), ((1 << 29) + 12, "=" * 30, "GTAC" * 7 + "GT")])
+    both(ctx, device.pack_host(far), NONE)
