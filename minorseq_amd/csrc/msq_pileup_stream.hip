@@ -36,6 +36,9 @@
 // MSQ_EXP: compile-time timing experiments only (make EXTRA=-DMSQ_EXP=n); any non-zero value gives WRONG counts.
 // bit 0 skip the LDS ORs of phase 1, bit 1 skip phase 2 + drain, bit 2 skip the squeeze, bit 3 skip the drain,
 // bit 4 skip zero_rows, bit 5 skip the counter transposition of the flush.  The shipped library is always built with 0.
+#ifndef MSQ_NO_CARRIER
+#define MSQ_NO_CARRIER 0  // experiment builds: any base a read carries can be the runner-up of its column
+#endif
 #ifndef MSQ_NO_IDX
 #define MSQ_NO_IDX 0  // experiment builds: ignore the sets' column index
 #endif
@@ -86,6 +89,7 @@ struct StreamArgs {
     int32_t RD;          // words per LDS row: a margin word, the slab's G words, two margin words, a zero pad word
     uint32_t normalized; // MSQ_READS_NORMALIZED: consuming bases lead every group, no compaction needed
     uint32_t alt_on;     // the launch has LDS for the alt-haplotype counters (one u32 per slab column)
+    uint32_t carrier;    // alt haplotype by the carrier rule (learn_alt_words: ~4 us per launch, for launches that are long enough)
     uint32_t flush_wide; // the LDS holds the counter levels of all passes at once (flush in one round)
     uint32_t* nuc;
     uint32_t* codon;
@@ -280,15 +284,58 @@ __device__ __forceinline__ uint32_t sliced_gt(const uint32_t (&a)[L], const uint
     return gt;
 }
 
+// Rank the four bases of every column of a word by their bit-sliced counts: best = the most common base (the smaller
+// code among equals), second = the most common of the OTHER bases that `ok` admits (0 where it admits none).
+__device__ __forceinline__ void rank_bases(const uint32_t (&cnt)[4][8], const uint32_t (&ok)[4], uint32_t& any, uint32_t (&best)[4],
+                                           uint32_t (&second)[4], uint32_t& has_alt)
+{
+    any = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) any |= cnt[b][l];
+    // beats(i, j): base i ranks before base j -- the larger count, the smaller index among equals
+    uint32_t beats[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) {
+            const uint32_t later_wins = sliced_gt(cnt[j], cnt[i]);
+            beats[j][i] = later_wins;
+            beats[i][j] = ~later_wins;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t m = any;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j != i) m &= beats[i][j];
+        best[i] = m;
+    }
+    has_alt = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t m = any & ~best[i] & ok[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j != i) m &= best[j] | ~ok[j] | beats[i][j];  // ahead of every other admitted base
+        second[i] = m;
+        has_alt |= m;
+    }
+}
+
 // The workgroup's guide, learnt from every wave's first batch (64 .. 96 reads): per column the most common base
-// -> gl[G + 3][4] = (valid, code bit 0, code bit 1, 0) -- and the runner-up, if any read carries a second base (a
-// minor variant at >= ~3 % is caught by most workgroups; a sequencing error caught instead costs nothing, it is an
-// alt that never matches again) -> the ALT haplotype gl2[G + 3][4] = (valid, bit 0, bit 1, has-a-runner-up): the
-// runner-up's base where there is one, the guide's base elsewhere.  Cells that match the guide
+// -> gl[G + 3][4] = (valid, code bit 0, code bit 1, 0) -- and the ALT haplotype gl2[G + 3][4] = (valid, bit 0, bit 1,
+// has-a-runner-up): the runner-up's base where there is one, the guide's base elsewhere.  Cells that match the guide
 // are counted in registers; cells that deviate from it but match the alt haplotype are counted in LDS (the drain);
-// only what matches neither costs a global atomic.  Runs once per workgroup; kept out of line so its registers do
-// not add to the streaming loop's budget.  Rows are [8][RD][4 planes V X B0 B1], WV dwords per wave.
-__device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl, uint32_t* gl2, int NWV, int WV, int RD, int G, int tid, int T)
+// only what matches neither costs a global atomic.  Which runner-up counts:
+//   cnt_tmp == nullptr: any base a read carries (decided here).
+//   cnt_tmp != nullptr: decided later by learn_alt_words, which needs the counts: they are parked in cnt_tmp
+//   ([32][G + 1] dwords, conflict-free) and gl2 is left alone.
+// Runs once per workgroup; kept out of line so its registers do not add to the streaming loop's budget.  Rows are
+// [8][RD][4 planes V X B0 B1], WV dwords per wave.
+__device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl, uint32_t* gl2, uint32_t* cnt_tmp, int NWV, int WV, int RD,
+                                               int G, int tid, int T)
 {
     const int ROWB = RD * 4;
     for (int cg = tid; cg <= G; cg += T) {  // word G = the first word behind the slab: codons reach into it
@@ -310,45 +357,74 @@ __device__ __noinline__ void learn_guide_words(const uint32_t* lds, uint32_t* gl
 #pragma unroll
             for (int b = 0; b < 4; ++b) counter_add8(cnt[b], x[b]);
         }
-        uint32_t any = 0, seen[4];  // seen: at least one read carries the base
+        uint32_t any, best[4], second[4], has_alt, seen[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             seen[b] = 0;
 #pragma unroll
             for (int l = 0; l < 8; ++l) seen[b] |= cnt[b][l];
-            any |= seen[b];
         }
-        // beats(i, j): base i ranks before base j -- the larger count, the smaller index among equals
-        uint32_t beats[4][4];
+        rank_bases(cnt, seen, any, best, second, has_alt);
+        const uint32_t g0 = best[1] | best[3], g1 = best[2] | best[3];
+        *reinterpret_cast<uint4*>(gl + cg * 4) = make_uint4(any, g0, g1, 0u);
+        if (cnt_tmp) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int j = i + 1; j < 4; ++j) {
-                const uint32_t later_wins = sliced_gt(cnt[j], cnt[i]);
-                beats[j][i] = later_wins;
-                beats[i][j] = ~later_wins;
+                for (int l = 0; l < 8; ++l) cnt_tmp[(b * 8 + l) * (G + 1) + cg] = cnt[b][l];
+        } else {
+            const uint32_t a0 = second[1] | second[3], a1 = second[2] | second[3];
+            *reinterpret_cast<uint4*>(gl2 + cg * 4) = make_uint4(any, (has_alt & a0) | (~has_alt & g0), (has_alt & a1) | (~has_alt & g1), has_alt);
+        }
+    }
+}
+
+// The alt haplotype with the CARRIER rule (after the first batch's phase 2 has counted, per row, the bases that miss
+// the guide -- rowdev[NWV * 8]): a runner-up base counts when at least two reads carry it, or when one of its reads
+// is a carrier -- a read that misses the guide in kCarrierMin columns or more, i.e. a read of another haplotype, not
+// a read with a sequencing error.  One read's error (3 % of the columns at 0.05 % errors among 64 reads) then no
+// longer stands as the runner-up of its column, where it made every read of a real minor variant next to it miss
+// the alt CODON and pay global atomics; and a minor variant seen in a single read still teaches all its columns.
+constexpr uint32_t kCarrierMin = 6;
+constexpr int kCarrierMinBatches = 16;
+__device__ __noinline__ void learn_alt_words(const uint32_t* lds, const uint32_t* gl, uint32_t* gl2, uint32_t* cnt_tmp, const uint32_t* rowdev,
+                                             int NWV, int WV, int RD, int G, int tid, int T)
+{
+    const int ROWB = RD * 4, lane = tid & 63, rows = NWV * kRows;  // rows <= 96
+    const uint64_t car0 = __ballot(lane < rows && rowdev[min(lane, rows - 1)] >= kCarrierMin);
+    const uint64_t car1 = __ballot(lane + 64 < rows && rowdev[min(lane + 64, rows - 1)] >= kCarrierMin);
+    for (int cg = tid; cg <= G; cg += T) {
+        uint32_t cnt[4][8];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                cnt[b][l] = cnt_tmp[(b * 8 + l) * (G + 1) + cg];
+                cnt_tmp[(b * 8 + l) * (G + 1) + cg] = 0;  // the area becomes the alt counters: all zero
             }
-        uint32_t best[4], second[4], has_alt = 0;
+        uint32_t ok[4];  // at least two reads
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t m = any;
+        for (int b = 0; b < 4; ++b) {
+            ok[b] = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j != i) m &= beats[i][j];
-            best[i] = m;
+            for (int l = 1; l < 8; ++l) ok[b] |= cnt[b][l];
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t m = any & ~best[i] & seen[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j != i) m &= best[j] | beats[i][j];
-            second[i] = m;
-            has_alt |= m;
+        for (int half = 0; half < 2; ++half) {  // ... or a carrier's base
+            uint64_t m = half ? car1 : car0;
+            while (m) {
+                const int r = 64 * half + (__ffsll((long long)m) - 1);
+                m &= m - 1;
+                const uint4 w = *reinterpret_cast<const uint4*>(lds + (r >> 3) * WV + (r & 7) * ROWB + (cg + 1) * 4);
+                ok[0] |= w.x & ~w.z & ~w.w;
+                ok[1] |= w.x & w.z & ~w.w;
+                ok[2] |= w.x & ~w.z & w.w;
+                ok[3] |= w.x & w.z & w.w;
+            }
         }
+        uint32_t any, best[4], second[4], has_alt;
+        rank_bases(cnt, ok, any, best, second, has_alt);
         const uint32_t g0 = best[1] | best[3], g1 = best[2] | best[3];
         const uint32_t a0 = second[1] | second[3], a1 = second[2] | second[3];
-        *reinterpret_cast<uint4*>(gl + cg * 4) = make_uint4(any, g0, g1, 0u);
         *reinterpret_cast<uint4*>(gl2 + cg * 4) = make_uint4(any, (has_alt & a0) | (~has_alt & g0), (has_alt & a1) | (~has_alt & g1), has_alt);
     }
 }
@@ -606,8 +682,10 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     uint32_t* const draw_ctr = lds + NWV * WV;                // the workgroup's batch counter (BatchDraw)
     uint32_t* const gl = draw_ctr + 4;                        // the workgroup's guide words [G + 3][4]
     uint32_t* const gl2 = gl + 4 * (G + 3);                   // the alt haplotype [G + 3][4] (learn_guide_words)
-    uint32_t* const altc = gl2 + 4 * (G + 3);                 // [G * 32] per column: alt nucleotide count | alt codon count << 16
+    uint32_t* const altc = gl2 + 4 * (G + 3);                 // [(G + 1) * 32] per column: alt nucleotide count | alt codon count << 16
+    uint32_t* const rowdev = altc + (G + 1) * 32;             // [96] per row of the first batches: bases that miss the guide (learn_alt_words)
     const bool alt_on = !PHASE && a.alt_on != 0;
+    const bool carrier = alt_on && a.carrier != 0;
 
     // ---- phase-2 identity: in pass p this lane owns word cgp[p].  The last pass, when at most 32 words wide,
     // splits the batch's rows between the two halves of the wave (rows rbase .. rbase+3).
@@ -647,7 +725,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
             gl[2 * i + 1] = (uint32_t)a.ph_idx[i];
         }
     } else {
-        for (int i = tid; i < 8 * (G + 3) + (alt_on ? G * 32 : 0); i += T) gl[i] = 0;  // guide, alt haplotype, alt counters
+        for (int i = tid; i < 8 * (G + 3) + (alt_on ? (G + 1) * 32 + 96 : 0); i += T) gl[i] = 0;  // guide, alt haplotype, alt counters, rowdev
     }
     __syncthreads();
     BatchDraw bd;
@@ -945,8 +1023,30 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     // ---- the workgroup's guide = per-column majority base over every wave's first batch
     auto learn_guide = [&]() {
         __syncthreads();  // every wave's first batch is in its rows
-        learn_guide_words(lds, gl, gl2, NWV, WV, RD, G, tid, T);
+        learn_guide_words(lds, gl, gl2, carrier ? altc : nullptr, NWV, WV, RD, G, tid, T);
         __syncthreads();
+    };
+    // ---- the alt haplotype (two more workgroup barriers, met by every wave, before the counters come to life).  First
+    // how far each read of this wave's first batch is from the guide: lane = word, as in phase 2, bases that miss the
+    // guide's, summed per row with an LDS add where there are any
+    auto learn_alt = [&](const bool have_batch) {
+        if (have_batch) {
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                if (!act[p]) continue;
+                const bool sp = p == PASSES - 1 && split;
+                const uint4 g4 = *reinterpret_cast<const uint4*>(gl + cgp[p] * 4);
+                for (int i = 0; i < (sp ? 4 : kRows); ++i) {
+                    const int row = (sp ? rbase : 0) + i;
+                    const uint4 lo = *reinterpret_cast<const uint4*>(wrow + row * ROWB + (cgp[p] + 1) * 4);
+                    const uint32_t nd = lo.x & ~(g4.x & ~((lo.z ^ g4.y) | (lo.w ^ g4.z)));
+                    if (nd) atomicAdd(&rowdev[wave * kRows + row], (uint32_t)__popc(nd));
+                }
+            }
+        }
+        __syncthreads();  // every wave's rowdev counts are in
+        learn_alt_words(lds, gl, gl2, altc, rowdev, NWV, WV, RD, G, tid, T);
+        __syncthreads();  // the alt words are there before any drain looks at them
     };
 
     // ---- the stream: slot k holds chunk k, k + NS, ...; a slot is refilled right after its chunk is decoded
@@ -994,6 +1094,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     MSQ_TR();
     if (!PHASE) {
         learn_guide();
+        if (carrier) learn_alt(have);
         if (with_bounds && tid == 0) {  // one atomic pair per workgroup; the last workgroup in publishes and clears
             atomicMax(&a.bounds_acc[0], draw_ctr[1]);
             atomicMax(&a.bounds_acc[1], draw_ctr[2]);
@@ -1425,7 +1526,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
         // no wave) one alt counter per slab column
         const size_t guide_lds = 16 + std::max((size_t)(G + 3) * 32, (size_t)ph_n * 8);
         const int max_waves_probe = max_waves_of(np_kernel, passes);
-        const size_t alt_lds = (size_t)G * 32 * 4;
+        const size_t alt_lds = ((size_t)(G + 1) * 32 + 96) * 4;  // alt counters (first: the parked base counts), rowdev
         const bool alt_on = !MSQ_NO_ALT && !phase && std::min<size_t>(max_waves_probe, (160 * 1024 - guide_lds - alt_lds - 512) / wave_lds) ==
                                           std::min<size_t>(max_waves_probe, (160 * 1024 - guide_lds - 512) / wave_lds);
         const size_t shared_lds = guide_lds + (alt_on ? alt_lds : 0);
@@ -1482,6 +1583,12 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
             a.read_lo = lo;
             a.read_hi = hi;
             a.n_batches = n_batches;
+            // the carrier rule costs two workgroup barriers and a second pass over the counts (~4 us per launch): for
+            // launches of at least kCarrierMinBatches batches per wave
+            // (MSQ_CARRIER_MIN_BATCHES in the environment overrides the threshold: the tests run small sets through both rules)
+            const char* env_min = getenv("MSQ_CARRIER_MIN_BATCHES");
+            const uint64_t min_batches = env_min ? (uint64_t)strtoull(env_min, nullptr, 10) : (uint64_t)kCarrierMinBatches;
+            a.carrier = (!MSQ_NO_CARRIER && n_batches >= min_batches * w * n_wg) ? 1u : 0u;
             if (fused) {  // deviations into the context's matrix; the fold stores the sum and clears that matrix again
                 a.nuc = fused->d_dev;
                 a.codon = fused->d_dev + (size_t)W * 6;
