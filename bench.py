@@ -25,7 +25,7 @@ BASELINE config #3 states it; with N > 1 the weak line also carries the strong m
 
 Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the read-streaming pileup kernel) timed with
 HIP events on its own stream inside the timed region (every --time-every-th step: an event pair costs the stream
-~10 us of bubbles); `cpu_baseline` is the oracle (CPU restatement of the reference path) on a bounded sample,
+~10 us of bubbles; the median over the timed steps, 25 of them by default); `cpu_baseline` is the oracle (CPU restatement of the reference path) on a bounded sample,
 rank 0 at N = 1 only.
 """
 import argparse
@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pol_1m", help="pol_1m (default: 1M x 2843, north-star target), pol_100k, "
                     "hiv_mix_200k, amp20k_10m")
@@ -261,13 +261,18 @@ class Run:
         ms = (C.c_float * n_slots)()
         n_ms = C.c_int32(0)
         path_ms = None
+        def median(v):
+            v = sorted(v)
+            return 0.0 if not v else v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
         if self.launches_per_step == 1:
             abi.check(L.msq_timing_read_path(ctx.h, ms, n_slots, C.byref(n_ms)))
-            path_ms = sum(ms[:n_ms.value]) / max(1, n_ms.value)
+            path_ms = median(ms[:n_ms.value])
         abi.check(L.msq_timing_read(ctx.h, ms, n_slots, C.byref(n_ms)))
         abi.check(L.msq_timing_enable(ctx.h, 0))
-        timed_steps = max(1, n_ms.value // self.launches_per_step)
-        kernel_ms = sum(ms[:n_ms.value]) / timed_steps  # per step: the slab launches of a partition added up
+        k = self.launches_per_step
+        timed_steps = max(1, n_ms.value // k)
+        # per timed step: the slab launches of a partition added up; the median over the timed steps
+        kernel_ms = median([sum(ms[i * k:(i + 1) * k]) for i in range(n_ms.value // k)])
         return dt, kernel_ms, path_ms, timed_steps
 
     def verify(self):

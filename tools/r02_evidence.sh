@@ -15,6 +15,7 @@ print("%-34s step %.4f ms  K1 %.4f  path %s  frac %.3f  phys %s  verified %s" % 
 PY
 }
 line bench_default --verify &&
+line bench_default_h2d --h2d-steps 5 --cpu-sample 0 --verify &&
 line bench_pol_125k_force_dist --reads 125000 --force-dist --verify --cpu-sample 0 --steps 200 &&
 line bench_pol_125k_force_dist_unfused --reads 125000 --force-dist --unfused --verify --cpu-sample 0 --steps 200 &&
 line bench_pol_100k --workload pol_100k --verify --cpu-sample 0 --steps 200 &&
