@@ -23,6 +23,11 @@ read index = rank * reads + i.  "strong": the workload's reads split over the ra
 BASELINE config #3 states it; with N > 1 the weak line also carries the strong measurement of the same run as
 `strong_scaling`, and --scaling strong makes it the line's `value`.
 
+Set-up (untimed: generating and packing the reads, their column index, the plan, the log-factorial table) ends with
+--spinup-ms of untimed steps (default 80 ms): the GPU needs ~50 ms of load before its clocks are up, and 20 steps
+behind 5 warm-up steps read 7 % slower than the same steps inside a long run.  `config.clock_spinup` says what ran;
+--spinup-ms 0 turns it off.  The W warm-up steps and exactly K timed steps follow.
+
 Prints ONE JSON line (rank 0).  `roofline` is the dominant kernel (the read-streaming pileup kernel) timed with
 HIP events on its own stream inside the timed region (every --time-every-th step: an event pair costs the stream
 ~10 us of bubbles; the median over the timed steps, 25 of them by default); `cpu_baseline` is the oracle (CPU restatement of the reference path) on a bounded sample,
@@ -68,6 +73,9 @@ def parse():
     ap.add_argument("--exchange", default="lib", choices=["lib", "torch"], help="N > 1: the library's RCCL communicator "
                     "(msq_comm_*) or, for comparison, torch.distributed's RCCL group (also the fallback when the "
                     "library communicator cannot be made; the line's config.exchange says which ran)")
+    ap.add_argument("--spinup-ms", type=float, default=80.0, help="set-up ends with untimed steps for this long: the GPU "
+                    "needs ~50 ms of load before its clocks are up (20 steps after 5 warm-ups read 7 %% slower than the "
+                    "same steps in a long run); 0 = none.  The W warm-up steps and the K timed steps follow as given")
     ap.add_argument("--time-every", type=int, default=4, help="HIP events around the pileup kernel in every n-th step")
     ap.add_argument("--verify", action="store_true", help="after the timed loop: the count matrices of the last step "
                     "against the independent simple kernel's (bit for bit)")
@@ -239,8 +247,20 @@ class Run:
             ex.allreduce_counts(self.counts)
         self.cells()
 
-    def timed(self, barrier):
+    def timed(self, barrier, agree=lambda x: x):
         a, abi, L, ctx = self.a, self.abi, self.L, self.ctx
+        self.spinup_steps = 0
+        if a.spinup_ms > 0:  # clocks up (set-up, like packing the reads).  A step holds collectives: every rank runs the
+            t_up = time.perf_counter()  # same number of steps -- eight to see how long one takes, then what the ranks agree on
+            for _ in range(8):
+                self.step()
+            ctx.sync()
+            t8 = max(time.perf_counter() - t_up, 1e-6)
+            more = int(agree(min(20000.0, max(0.0, a.spinup_ms * 1e-3 / t8 * 8.0 - 8.0))))
+            for _ in range(more):
+                self.step()
+            ctx.sync()
+            self.spinup_steps = 8 + more
         for _ in range(a.warmup):
             self.step()
         abi.check(L.msq_pileup_check(ctx.h))
@@ -381,7 +401,7 @@ def main():
             first, n = sharding.shard_range(reads, rank, world)
             total = reads
         run = Run(a, ctx, ex, wl, first, n, total, None)
-        dt, kernel_ms, path_ms, timed_steps = run.timed(barrier)
+        dt, kernel_ms, path_ms, timed_steps = run.timed(barrier, max_over_ranks)
         dt = max_over_ranks(dt)
         verified = run.verify() if a.verify else None
         return run, total, dt, kernel_ms, path_ms, timed_steps, verified
@@ -461,6 +481,8 @@ def main():
                 "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 127) // 128),
                 "read_layout": "column-slab partition (built at set-up)" if n_slabs else "one read set",
                 "qv_thresholds": "unset" if a.qualqv < 0 and not a.rich else "applied at pack time (baked; the bake pass is set-up, not timed)" if baked else "applied in every pass",
+                "clock_spinup": ("%d untimed steps (%.0f ms) at the end of set-up, before the warm-up steps" % (run.spinup_steps, a.spinup_ms)
+                                 if run.spinup_steps else "none"),
                 "bases_per_gpu": int(n_bases), "codon_positions": P, "number_of_tests": n_tests,
                 "bases_off_majority": dev_share},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
