@@ -638,6 +638,12 @@ struct BatchConsumer {
 // MANY_N: Ns are common (a QV mask, applied here or baked into the planes at pack time): they get a counter of
 // their own instead of going down the deviation path.
 // IDX: the set carries the group column index (msq_reads_index), see phase 1.
+#ifdef MSQ_WGT  // timing experiment: when each workgroup of the last launch started [wg], when the last of its waves
+// ended [1024 + wg] and when the last of its waves left the batch loop [2048 + wg] (100 MHz); read back with
+// msq_debug_wgt (tools/wgt.py)
+static __device__ unsigned long long g_wgt[3 * 1024];
+extern "C" int msq_debug_wgt(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgt), sizeof(g_wgt)); }
+#endif
 template <int NP, int PASSES, bool PHASE, bool MANY_N = (NP != 0), bool IDX = false>
 __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(StreamArgs a)
 {
@@ -659,6 +665,13 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
 #define MSQ_TA(k) ((void)0)
 #endif
     MSQ_TR();
+#ifdef MSQ_WGT
+    if (!PHASE && threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_wgt[blockIdx.x] = wall_clock64();
+        g_wgt[1024 + blockIdx.x] = 0;
+        g_wgt[2048 + blockIdx.x] = 0;
+    }
+#endif
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, NWV = T >> 6;
     const int wave = (int)uni((uint32_t)tid >> 6);   // tell the compiler it is wave-uniform: all stream control is scalar
     const int RD = a.RD, G = a.G;
@@ -1153,6 +1166,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     // up while still bit-sliced (two bitop3 per level and counter, against some sixty instructions per counter to
     // transpose it), one wave per counter, and only the sum is transposed and stored as this workgroup's partial
     MSQ_TR();
+#ifdef MSQ_WGT
+    if (lane == 0 && blockIdx.x < 1024) atomicMax(&g_wgt[2048 + blockIdx.x], (unsigned long long)wall_clock64());
+#endif
     __syncthreads();
     MSQ_TR();
     const int cols = G * 32;
@@ -1259,6 +1275,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     }
     if (exotic) my_err |= DEVERR_EXOTIC;
     if (my_err) atomicOr(a.err, my_err);
+#ifdef MSQ_WGT
+    if (lane == 0 && blockIdx.x < 1024) atomicMax(&g_wgt[1024 + blockIdx.x], (unsigned long long)wall_clock64());
+#endif
 #ifdef MSQ_TRACE
     MSQ_TR();
     for (int d = 32; d >= 1; d >>= 1) {

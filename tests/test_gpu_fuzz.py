@@ -2,6 +2,8 @@
 insertion rates, QV thresholds, layouts -- pileup counts, window bounds, cells, insertion histogram and phasing
 keys, every one against the oracle.  Small cases find the border conditions the big synthetic workloads never
 reach (windows narrower than a codon, reads that are one base long, columns nobody covers)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -29,7 +31,11 @@ def case_of(seed):
     return reads, thr, W
 
 
-@pytest.mark.parametrize("seed", range(150))
+# MSQ_FUZZ_FIRST / MSQ_FUZZ_N: another seed range for a one-off longer run (the default 150 are what the suite runs)
+_FIRST, _N = int(os.environ.get("MSQ_FUZZ_FIRST", "0")), int(os.environ.get("MSQ_FUZZ_N", "150"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + _N))
 def test_fuzz(ctx, seed):
     reads, thr, W = case_of(seed)
     m = orc.Msa(reads, thr)
@@ -43,6 +49,11 @@ def test_fuzz(ctx, seed):
             nuc, codon = device.pileup(ctx, dr, q, b0, m.W, mode=mode)
             assert (nuc.cpu().numpy()[:m.W * 6].reshape(-1, 6) == m.nuc_counts()).all(), (plain, mode)
             assert (codon.cpu().numpy()[:m.W * 64].reshape(-1, 64) == m.codon_counts()).all(), (plain, mode)
+        if packed["n_groups"]:  # the same set with a group column index: the kernels that skip the prefix sum
+            idx = device.upload(packed, ctx.device, ctx=ctx)
+            nuc, codon = device.pileup(ctx, idx, q, b0, m.W)
+            assert (nuc.cpu().numpy()[:m.W * 6].reshape(-1, 6) == m.nuc_counts()).all(), ("index", plain)
+            assert (codon.cpu().numpy()[:m.W * 64].reshape(-1, 64) == m.codon_counts()).all(), ("index", plain)
         if not (dr.flags & abi.MSQ_READS_HAS_EXOTIC):  # the window left in HBM, matrices wider than the window
             bounds = device.window_bounds_device(ctx, dr)
             nuc, codon = device.pileup_device_window(ctx, dr, q, bounds, b0, m.W + seed % 5)
