@@ -206,7 +206,7 @@ class Run:
         self.part = None
         if (W > 4096 or 0 < a.slab_columns < W) and not a.no_partition and a.mode != "simple":
             self.part = device.Partition(ctx, dr, b0, W, a.slab_columns)
-        self.launches_per_step = self.part.n_slabs if self.part else 1  # timing slots: one per pileup call that reaches the kernel
+        self.launches_per_step = 1  # timing records per step: counted before the timed steps (run)
         self.flow = "host" if (a.window == "host" or (a.mode == "simple" and a.window == "device")) else a.window
         if self.part and self.flow == "device":
             self.flow = "known"  # a partition is laid out for its window
@@ -265,6 +265,14 @@ class Run:
             self.step()
         abi.check(L.msq_pileup_check(ctx.h))
         abi.check(L.msq_call_check(ctx.h))
+        # timing records per step: one per pileup call that reaches the kernel -- a partition's slabs take one launch
+        # together where the library can merge them, else one each; counted on one more untimed step
+        abi.check(L.msq_timing_enable(ctx.h, 256))
+        self.step()
+        probe, n_probe = (C.c_float * 256)(), C.c_int32(0)
+        abi.check(L.msq_timing_read(ctx.h, probe, 256, C.byref(n_probe)))
+        abi.check(L.msq_timing_enable(ctx.h, 0))
+        self.launches_per_step = max(1, n_probe.value)
         stride = 1 if self.launches_per_step > 1 else max(1, min(a.time_every, a.steps))
         n_slots = (a.steps * self.launches_per_step + stride - 1) // stride
         abi.check(L.msq_timing_enable_strided(ctx.h, n_slots, stride))
@@ -479,6 +487,7 @@ def main():
                 "exchange": (ex_note or ("one RCCL group per step (bounds MAX + counts SUM), library communicator" if flow == "known"
                                           else "two RCCL all-reduces per step, library communicator")) if multi else "none (one GPU)",
                 "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 127) // 128),
+                "pileup_launches_per_step": run.launches_per_step,
                 "read_layout": "column-slab partition (built at set-up)" if n_slabs else "one read set",
                 "qv_thresholds": "unset" if a.qualqv < 0 and not a.rich else "applied at pack time (baked; the bake pass is set-up, not timed)" if baked else "applied in every pass",
                 "clock_spinup": ("%d untimed steps (%.0f ms) at the end of set-up, before the warm-up steps" % (run.spinup_steps, a.spinup_ms)

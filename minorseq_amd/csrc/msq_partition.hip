@@ -19,6 +19,8 @@
 void msq_slab_layout(int32_t W, int max_words, int* n_slabs, int* Gslab);
 int msq_pileup_stream_slab_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0,
                                   int32_t W, int slab, int slab_words, uint32_t* d_nuc, uint32_t* d_codon, bool* handled);
+int msq_pileup_stream_slabs_launch(msq_ctx* ctx, const msq_packed_reads* const* sets, int n_sets, const msq_qv_thresholds& thr,
+                                   int32_t win_begin0, int32_t W, int slab_words, uint32_t* d_nuc, uint32_t* d_codon, bool* handled);
 
 struct msq_partition {
     int32_t win_begin0 = 0, W = 0;
@@ -270,6 +272,13 @@ extern "C" int msq_pileup_partition(msq_ctx* ctx, const msq_partition* p, const 
         if (t < -1 || t > 255) return msq_fail(MSQ_ERR_ARG, "msq_pileup_partition: QV threshold %d out of range", t);
     }
     MSQ_HIP(hipSetDevice(ctx->device));
+    {  // all slabs in one launch where that applies (the per-launch costs are paid once)
+        std::vector<const msq_packed_reads*> views;
+        for (const msq_packed_dev* d : p->sets) views.push_back(&d->view);
+        bool handled = false;
+        int rc = msq_pileup_stream_slabs_launch(ctx, views.data(), (int)views.size(), *thr, p->win_begin0, p->W, p->slab_words, d_nuc, d_codon, &handled);
+        if (rc != MSQ_OK || handled) return rc;
+    }
     for (int s = 0; s < (int)p->sets.size(); ++s) {
         const msq_packed_reads& v = p->sets[s]->view;
         if (v.n_reads == 0) continue;

@@ -73,6 +73,22 @@ constexpr int max_waves_of(int np, int passes) { return ((passes == 1 && np <= 2
 // Register slots of the chunk pipeline (NS - 1 chunk loads in flight behind the chunk being decoded).
 constexpr int slots_of(int np, int /*passes*/) { return np == 0 ? MSQ_NS0 : np == 1 ? 3 : 2; }
 
+// One column slab of a MERGED launch (pileup_kernel<.., MERGED = true>): a launch over several slabs at once, each with
+// a share of the workgroups, so that a wide window pays the per-launch costs (dispatch, the guide, the flush: ~30 us)
+// once and not once per slab.  The slab's read set (its own with a partition, else the same for all), its geometry,
+// its partials and its workgroups [wg_first, wg_first + wg_count).
+constexpr int kMaxMerged = 8;
+struct SlabDesc {
+    const int32_t* ref_start;
+    const uint64_t* group_off;
+    const uint4* bop;
+    const uint32_t* gcol;
+    uint32_t* partials;  // [wg_count][NC + 4][G*32]
+    uint64_t n_reads, n_batches;
+    int32_t slab0, G;
+    uint32_t wg_first, wg_count;
+};
+
 struct StreamArgs {
     const int32_t* ref_start;
     const uint64_t* group_off;
@@ -93,7 +109,7 @@ struct StreamArgs {
     uint32_t flush_wide; // the LDS holds the counter levels of all passes at once (flush in one round)
     uint32_t* nuc;
     uint32_t* codon;
-    uint32_t* partials;  // [gridDim.x][NC + 4][G*32]
+    uint32_t* partials;  // [workgroups][NC + 4][G*32]
     uint32_t* err;
     // the phasing gather (pileup_kernel<.., PHASE = true>): window positions whose codon starts in this slab
     const int32_t* ph_pos;  // [ph_n] CodonAt arguments (window columns)
@@ -105,6 +121,9 @@ struct StreamArgs {
     const int32_t* ref_end;
     uint32_t* bounds_acc;   // {max of ~begin, max of end, workgroups done}, order-encoded; left at zero
     int32_t* bounds_out;    // {-begin0, end0}
+    // MERGED kernels: the slabs of the launch; the per-slab fields above are taken from here
+    uint32_t n_merged;
+    SlabDesc slabs[kMaxMerged];
 };
 
 __device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, int k)  // bits k.. of the 64-bit hi:lo
@@ -449,7 +468,7 @@ typedef const int32_t __attribute__((address_space(4))) * const_i32_ptr;
 // Which batches a wave takes.  The waves of a workgroup do not run at the same speed (of the two waves of a SIMD the
 // older one wins the issue arbitration: with a fixed share per wave the older ones sat idle for the last ~13 % of
 // the kernel), so they DRAW their batches from one LDS counter: the t-th draw of the workgroup is batch
-// t * gridDim.x + blockIdx.x.  A draw is an LDS atomic whose result is looked at one batch later; the ids of the
+// t * (workgroups of the launch) + (this workgroup).  A draw is an LDS atomic whose result is looked at one batch later; the ids of the
 // wave's last few batches sit in one VGPR (lane s & 3 = the wave's s-th batch, ~0 = none left), where both the
 // producer (up to two batches ahead) and the consumer find them.  A wave stops drawing at `cap` batches, what its
 // bit-sliced counters hold.
@@ -477,11 +496,11 @@ struct BatchDraw {
         n_res = uni(n_res + 1u);
     }
     __device__ __forceinline__ uint32_t id(uint32_t s) const { return uni((uint32_t)__builtin_amdgcn_readlane((int)ring, (int)(s & 3u))); }
-    __device__ __forceinline__ void init(uint32_t* counter, uint32_t nb, uint32_t cap_, int lane)
+    __device__ __forceinline__ void init(uint32_t* counter, uint32_t nb, uint32_t cap_, int lane, uint32_t wg, uint32_t nwg)
     {
         ctr = counter;
-        stride = gridDim.x;
-        first = blockIdx.x;
+        stride = nwg;
+        first = wg;
         n_batches = nb;
         cap = cap_;
         ring = 0xffffffffu;
@@ -644,7 +663,8 @@ struct BatchConsumer {
 static __device__ unsigned long long g_wgt[3 * 1024];
 extern "C" int msq_debug_wgt(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgt), sizeof(g_wgt)); }
 #endif
-template <int NP, int PASSES, bool PHASE, bool MANY_N = (NP != 0), bool IDX = false>
+// MERGED: the launch covers several column slabs (StreamArgs::slabs), this workgroup works on one of them.
+template <int NP, int PASSES, bool PHASE, bool MANY_N = (NP != 0), bool IDX = false, bool MERGED = false>
 __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(StreamArgs a)
 {
     constexpr int NS = slots_of(NP, PASSES);
@@ -672,6 +692,30 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         g_wgt[2048 + blockIdx.x] = 0;
     }
 #endif
+    uint32_t wg = blockIdx.x, nwg = gridDim.x;  // this workgroup among those that share its reads
+    if constexpr (MERGED) {
+        // the table sits in the kernel arguments (this kernel's only parameter, at offset 0 of the segment): read it
+        // through the constant address space, i.e. with scalar loads at a scalar index
+        typedef const SlabDesc __attribute__((address_space(4))) * const_desc_ptr;
+        typedef const char __attribute__((address_space(4))) * const_char_ptr;
+        const const_desc_ptr tab = (const_desc_ptr)((const_char_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(StreamArgs, slabs));
+        uint32_t sl = 0;
+        while (sl + 1 < a.n_merged && wg >= tab[sl + 1].wg_first) ++sl;
+        const const_desc_ptr d = tab + sl;
+        a.ref_start = d->ref_start;
+        a.group_off = d->group_off;
+        a.bop = d->bop;
+        a.gcol = d->gcol;
+        a.partials = d->partials;
+        a.read_lo = 0;
+        a.read_hi = d->n_reads;
+        a.n_batches = d->n_batches;
+        a.slab0 = d->slab0;
+        a.G = d->G;
+        a.RD = d->G + 4;
+        wg -= d->wg_first;
+        nwg = d->wg_count;
+    }
     const int T = blockDim.x, tid = threadIdx.x, lane = tid & 63, NWV = T >> 6;
     const int wave = (int)uni((uint32_t)tid >> 6);   // tell the compiler it is wave-uniform: all stream control is scalar
     const int RD = a.RD, G = a.G;
@@ -742,7 +786,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     }
     __syncthreads();
     BatchDraw bd;
-    bd.init(draw_ctr, (uint32_t)a.n_batches, PHASE ? 0xffffffffu : (uint32_t)kMaxBatchesPerWave, lane);
+    bd.init(draw_ctr, (uint32_t)a.n_batches, PHASE ? 0xffffffffu : (uint32_t)kMaxBatchesPerWave, lane, wg, nwg);
 
     // ---- producer: one unconditional chunk load per call (clamped addresses, no predicate around the loads)
     ChunkProducer pr;
@@ -1172,7 +1216,7 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
     __syncthreads();
     MSQ_TR();
     const int cols = G * 32;
-    uint32_t* const part = a.partials + (size_t)blockIdx.x * (NC + 4) * cols;
+    uint32_t* const part = a.partials + (size_t)wg * (NC + 4) * cols;
     // per column what the counters stand for: the guide's (plane set 0) and the alt haplotype's (plane set 1)
     // nucleotide and codon bins; then the alt counts the drain collected in LDS
     auto meta_of = [&](const uint32_t* g, int c) -> uint32_t {
@@ -1423,6 +1467,16 @@ pileup_kernel_fn pick_kernel(int np, int passes, bool many_n, bool idx)
     }
     return np == 0 ? pileup_kernel<0, 2, false> : np == 1 ? pileup_kernel<1, 2, false> : np == 2 ? pileup_kernel<2, 2, false> : pileup_kernel<4, 2, false>;
 }
+// the launches over several column slabs at once: the kernels a run takes (no QV planes in the loop)
+pileup_kernel_fn pick_merged_kernel(int passes, bool many_n, bool idx)
+{
+    if (idx) {
+        if (many_n) return passes == 1 ? pileup_kernel<0, 1, false, true, true, true> : pileup_kernel<0, 2, false, true, true, true>;
+        return passes == 1 ? pileup_kernel<0, 1, false, false, true, true> : pileup_kernel<0, 2, false, false, true, true>;
+    }
+    if (many_n) return passes == 1 ? pileup_kernel<0, 1, false, true, false, true> : pileup_kernel<0, 2, false, true, false, true>;
+    return passes == 1 ? pileup_kernel<0, 1, false, false, false, true> : pileup_kernel<0, 2, false, false, false, true>;
+}
 pileup_kernel_fn pick_phase_kernel(int np, bool idx)
 {
     if (np == 0 && idx) return pileup_kernel<0, 1, true, false, true>;
@@ -1459,6 +1513,153 @@ struct FusedStep {
 
 // fixed_partials: NULL, or a caller-provided buffer of fixed_bytes for the workgroup partials (msq_pileup_noalloc:
 // nothing is allocated then, and a launch that needs more is refused).
+// The pileup of a window of several column slabs as ONE launch + one fold per slab: every slab gets a share of the
+// workgroups in proportion to its groups.  sets[s] = the read set of slab s (a partition's own set per slab, or the
+// same set for every slab; NULL or empty = nothing to do for that slab).  *handled = false: not applicable (QV planes
+// in the loop, slabs that need different kernels, more reads than one launch counts, inputs too small to share the
+// chip) -- the caller takes one launch per slab.
+static int g_merged_launches = 0;  // launches taken by stream_launch_merged in this process (tests ask: did the merged path run?)
+extern "C" int msq_debug_merged_launches(void) { return g_merged_launches; }
+
+static int stream_launch_merged(msq_ctx* ctx, const msq_packed_reads* const* sets, int n_sets, const msq_qv_thresholds& thr,
+                                int32_t win_begin0, int32_t W, int slab_words, const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon,
+                                uint32_t* fixed_partials, size_t fixed_bytes, bool* handled)
+{
+    *handled = false;
+    if (getenv("MSQ_NO_MERGE")) return MSQ_OK;
+    const int Gtot = (W + 31) / 32;
+    int n_slabs = 0, Gslab = 0;
+    msq_slab_layout(W, slab_words, &n_slabs, &Gslab);
+    if (n_slabs < 2 || n_slabs != n_sets || n_slabs > kMaxMerged) return MSQ_OK;
+    StreamArgs a;
+    memset(&a, 0, sizeof(a));
+    uint32_t flags = 0;
+    bool have_flags = false, idx = !MSQ_NO_IDX && win_begin0 >= 0 && (int64_t)win_begin0 + W < 0x1fffff00;
+    int passes = 0, n_live = 0;
+    uint64_t total_groups = 0;
+    const int32_t thrs[4] = {thr.qual, thr.del, thr.sub, thr.ins};
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        const msq_packed_reads* R = sets[sl];
+        if (!R || R->n_reads == 0 || R->n_groups == 0) continue;
+        if (R->flags & MSQ_READS_HAS_EXOTIC) return MSQ_OK;
+        const uint8_t* planes[4] = {R->qual, R->delqv, R->subqv, R->insqv};
+        for (int k = 0; k < 4; ++k)
+            if (thrs[k] >= 0 && planes[k]) return MSQ_OK;  // a QV plane in the loop: those kernels are a fallback, one launch per slab
+        if (have_flags && R->flags != flags) return MSQ_OK;
+        flags = R->flags;
+        have_flags = true;
+        idx = idx && R->gcol != nullptr;
+        const int G = std::min(Gslab, Gtot - sl * Gslab);
+        const int ps = G <= 64 ? 1 : 2;
+        if (passes && ps != passes) return MSQ_OK;
+        passes = ps;
+        total_groups += R->n_groups;
+        ++n_live;
+    }
+    if (n_live < 2) return MSQ_OK;
+    const bool many_n = (flags & MSQ_READS_QV_BAKED) != 0;
+    const int NC = many_n ? 4 : 3;
+    // the LDS of the widest slab decides the waves per workgroup, as in a launch of its own
+    const int G = Gslab, RD = G + 4;
+    const size_t wave_lds = (size_t)kRows * RD * 16 + (size_t)((kRows * G * 2 + 15) / 16) * 16;
+    const size_t guide_lds = 16 + (size_t)(G + 3) * 32;
+    const int max_waves = max_waves_of(0, passes);
+    const size_t alt_lds = ((size_t)(G + 1) * 32 + 96) * 4;
+    const bool alt_on = !MSQ_NO_ALT && std::min<size_t>(max_waves, (160 * 1024 - guide_lds - alt_lds - 512) / wave_lds) ==
+                                           std::min<size_t>(max_waves, (160 * 1024 - guide_lds - 512) / wave_lds);
+    const size_t shared_lds = guide_lds + (alt_on ? alt_lds : 0);
+    const int w = (int)std::min<size_t>(max_waves, (160 * 1024 - shared_lds - 512) / wave_lds);
+    if (w < 1) return MSQ_OK;
+    const size_t slab_lds = (size_t)NC * w * kLevels * 256;
+    const bool flush_wide = slab_lds * passes <= 160 * 1024 - 512;
+    const size_t lds = std::max((size_t)w * wave_lds + shared_lds, flush_wide ? slab_lds * passes : slab_lds);
+
+    // workgroups per slab in proportion to its groups, at least one, n_cu in all
+    const int n_wg = ctx->n_cu;
+    if (n_wg < n_live) return MSQ_OK;
+    int share[kMaxMerged], given = 0, biggest = -1;
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        const msq_packed_reads* R = sets[sl];
+        share[sl] = 0;
+        if (!R || R->n_reads == 0 || R->n_groups == 0) continue;
+        share[sl] = std::max(1, (int)((double)n_wg * (double)R->n_groups / (double)total_groups));
+        given += share[sl];
+        if (biggest < 0 || R->n_groups > sets[biggest]->n_groups) biggest = sl;
+    }
+    share[biggest] += n_wg - given;
+    if (share[biggest] < 1) return MSQ_OK;
+    const char* env_min = getenv("MSQ_CARRIER_MIN_BATCHES");
+    const uint64_t min_batches = env_min ? (uint64_t)strtoull(env_min, nullptr, 10) : (uint64_t)kCarrierMinBatches;
+    bool carrier = !MSQ_NO_CARRIER;
+    size_t need = 0;
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        if (!share[sl]) continue;
+        const msq_packed_reads* R = sets[sl];
+        const uint64_t n_batches = (R->n_reads + kRows - 1) / kRows;
+        // too few batches to fill the slab's waves, or more reads than its waves' counters hold: one launch per slab
+        if (n_batches < (uint64_t)share[sl] * w || R->n_reads > (uint64_t)share[sl] * w * kMaxBatchesPerWave * kRows) return MSQ_OK;
+        carrier = carrier && n_batches >= min_batches * w * share[sl];
+        need += (size_t)share[sl] * (NC + 4) * std::min(Gslab, Gtot - sl * Gslab) * 32 * 4;
+    }
+    void* scratch_base = fixed_partials;
+    if (fixed_partials) {
+        if (need > fixed_bytes)
+            return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: %zu bytes of workgroup partials exceed the built-in %zu", need, fixed_bytes);
+    } else {
+        int rc = msq_scratch(ctx, need, &scratch_base);
+        if (rc != MSQ_OK) return rc;
+    }
+    a.win_begin0 = win_begin0;
+    a.W = W;
+    a.d_bounds = d_bounds;
+    a.normalized = (flags & MSQ_READS_NORMALIZED) ? 1u : 0u;
+    a.alt_on = alt_on ? 1u : 0u;
+    a.carrier = carrier ? 1u : 0u;
+    a.flush_wide = flush_wide ? 1u : 0u;
+    a.nuc = d_nuc;
+    a.codon = d_codon;
+    a.err = ctx->d_err;
+    for (int k = 0; k < 4; ++k) a.thr[k] = -1;
+    uint32_t wg_first = 0;
+    char* part = static_cast<char*>(scratch_base);
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        if (!share[sl]) continue;
+        const msq_packed_reads* R = sets[sl];
+        SlabDesc& d = a.slabs[a.n_merged++];
+        d.ref_start = R->ref_start;
+        d.group_off = R->group_off;
+        d.bop = reinterpret_cast<const uint4*>(R->bop);
+        d.gcol = idx ? R->gcol : nullptr;
+        d.partials = reinterpret_cast<uint32_t*>(part);
+        d.n_reads = R->n_reads;
+        d.n_batches = (R->n_reads + kRows - 1) / kRows;
+        d.slab0 = sl * Gslab * 32;
+        d.G = std::min(Gslab, Gtot - sl * Gslab);
+        d.wg_first = wg_first;
+        d.wg_count = (uint32_t)share[sl];
+        wg_first += d.wg_count;
+        part += (size_t)share[sl] * (NC + 4) * d.G * 32 * 4;
+    }
+    pileup_kernel_fn kern = pick_merged_kernel(passes, many_n, idx);
+    msq_timing_mark_begin(ctx);
+    if (lds > 48 * 1024)
+        MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
+    msq_timing_mark_end(ctx);
+    MSQ_HIP(hipGetLastError());
+    for (uint32_t k = 0; k < a.n_merged; ++k) {
+        const SlabDesc& d = a.slabs[k];
+        const int col_blocks = (d.G * 32 + kFoldCols - 1) / kFoldCols;
+        const int slices = std::max(1, std::min((int)d.wg_count / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, d.partials, (int)d.wg_count, NC,
+                           d.G * 32, d.slab0, W, d_nuc, d_codon, (uint32_t*)nullptr, (uint32_t*)nullptr);
+        MSQ_HIP(hipGetLastError());
+    }
+    ++g_merged_launches;
+    *handled = true;
+    return MSQ_OK;
+}
+
 static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
                          const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon, const PhaseRequest* phase, bool* handled,
                          int only_slab = -1, int slab_words = 128, uint32_t* fixed_partials = nullptr, size_t fixed_bytes = 0,
@@ -1516,6 +1717,12 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     a.bounds_acc = nullptr;
     a.bounds_out = nullptr;
     if (fused && (n_slabs != 1 || !R.ref_end)) return MSQ_OK;
+    if (!phase && !fused && only_slab < 0 && n_slabs > 1 && n_slabs <= kMaxMerged) {  // every slab streams the same set: one launch for all
+        const msq_packed_reads* same[kMaxMerged];
+        for (int sl = 0; sl < n_slabs; ++sl) same[sl] = &R;
+        int rc = stream_launch_merged(ctx, same, n_slabs, thr, win_begin0, W, slab_words, d_bounds, d_nuc, d_codon, fixed_partials, fixed_bytes, handled);
+        if (rc != MSQ_OK || *handled) return rc;
+    }
     bool marked = false;  // the timing slot opens with the first launch
     if (only_slab >= n_slabs) return msq_fail(MSQ_ERR_ARG, "msq_pileup_slab: slab %d of %d", only_slab, n_slabs);
     for (int slab = only_slab >= 0 ? only_slab : 0; slab < (only_slab >= 0 ? only_slab + 1 : n_slabs); ++slab) {
@@ -1649,6 +1856,13 @@ int msq_pileup_stream_slab_launch(msq_ctx* ctx, const msq_packed_reads& R, const
                                   int32_t W, int slab, int slab_words, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
 {
     return stream_launch(ctx, R, thr, win_begin0, W, nullptr, d_nuc, d_codon, nullptr, handled, slab, slab_words);
+}
+
+// every slab of a partition in one launch (msq_pileup_partition); *handled = false: one msq_pileup_stream_slab_launch per slab
+int msq_pileup_stream_slabs_launch(msq_ctx* ctx, const msq_packed_reads* const* sets, int n_sets, const msq_qv_thresholds& thr,
+                                   int32_t win_begin0, int32_t W, int slab_words, uint32_t* d_nuc, uint32_t* d_codon, bool* handled)
+{
+    return stream_launch_merged(ctx, sets, n_sets, thr, win_begin0, W, slab_words, nullptr, d_nuc, d_codon, nullptr, 0, handled);
 }
 
 // msq_pileup_step's streaming half; *handled = false: take msq_pileup_begin + msq_pileup instead
