@@ -660,7 +660,7 @@ struct BatchConsumer {
 #ifdef MSQ_WGT  // timing experiment: when each workgroup of the last launch started [wg], when the last of its waves
 // ended [1024 + wg] and when the last of its waves left the batch loop [2048 + wg] (100 MHz); read back with
 // msq_debug_wgt (tools/wgt.py)
-static __device__ unsigned long long g_wgt[3 * 1024];
+static __device__ unsigned long long g_wgt[6 * 1024];  // + wave 0: [3072 + wg] set up, [4096 + wg] first batch in the rows, [5120 + wg] guide learnt
 extern "C" int msq_debug_wgt(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgt), sizeof(g_wgt)); }
 #endif
 // MERGED: the launch covers several column slabs (StreamArgs::slabs), this workgroup works on one of them.
@@ -1147,8 +1147,14 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         }
     }
     MSQ_TR();
+#ifdef MSQ_WGT
+    if (tid == 0 && blockIdx.x < 1024) g_wgt[3072 + blockIdx.x] = wall_clock64();
+#endif
     if (have) chunks();
     MSQ_TR();
+#ifdef MSQ_WGT
+    if (tid == 0 && blockIdx.x < 1024) g_wgt[4096 + blockIdx.x] = wall_clock64();
+#endif
     if (!PHASE) {
         learn_guide();
         if (carrier) learn_alt(have);
@@ -1173,6 +1179,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
                 for (int l = 0; l < kLevels; ++l) cnt[p][k][l] = 0;
     }
     MSQ_TR();
+#ifdef MSQ_WGT
+    if (tid == 0 && blockIdx.x < 1024) g_wgt[5120 + blockIdx.x] = wall_clock64();
+#endif
     while (have) {  // a wave batch is complete in the rows
         MSQ_TA0();
         if (PHASE) {

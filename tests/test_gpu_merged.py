@@ -60,6 +60,13 @@ def test_one_set_and_partition(ctx, monkeypatch, name, n, kw):
     wide = device.pileup(ctx, dr, NONE, b, W, mode=abi.MSQ_PILEUP_SIMPLE)
     got = both_ways(monkeypatch, lambda: device.pileup(ctx, dr, NONE, b, W))
     assert torch.equal(got[0], wide[0]) and torch.equal(got[1], wide[1])
+    # the window left in HBM by the bounds kernel, matrices wider than the window (the slabs are cut from the capacity)
+    bounds = device.window_bounds_device(ctx, dr)
+    cap = wl.W + 777
+    got = both_ways(monkeypatch, lambda: device.pileup_device_window(ctx, dr, NONE, bounds, wl.win_begin0, cap))
+    assert bounds.tolist() == [-wl.win_begin0, wl.win_begin0 + wl.W]
+    assert torch.equal(got[0][:wl.W * 6], simple[0][:wl.W * 6]) and torch.equal(got[1][:wl.W * 64], simple[1][:wl.W * 64])
+    assert not got[0][wl.W * 6:].any() and not got[1][wl.W * 64:].any()
     part = device.Partition(ctx, dr, wl.win_begin0, wl.W)
     assert part.n_slabs > 1
     got = both_ways(monkeypatch, lambda: part.pileup(NONE))
