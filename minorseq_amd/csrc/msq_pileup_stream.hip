@@ -84,7 +84,7 @@ struct SlabDesc {
     const uint4* bop;
     const uint32_t* gcol;
     uint32_t* partials;  // [wg_count][NC + 4][G*32]
-    uint64_t n_reads, n_batches;
+    uint64_t read_lo, read_hi, n_batches;  // this launch's reads of the slab's set
     int32_t slab0, G;
     uint32_t wg_first, wg_count;
 };
@@ -707,8 +707,8 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
         a.bop = d->bop;
         a.gcol = d->gcol;
         a.partials = d->partials;
-        a.read_lo = 0;
-        a.read_hi = d->n_reads;
+        a.read_lo = d->read_lo;
+        a.read_hi = d->read_hi;
         a.n_batches = d->n_batches;
         a.slab0 = d->slab0;
         a.G = d->G;
@@ -1599,16 +1599,22 @@ static int stream_launch_merged(msq_ctx* ctx, const msq_packed_reads* const* set
     if (share[biggest] < 1) return MSQ_OK;
     const char* env_min = getenv("MSQ_CARRIER_MIN_BATCHES");
     const uint64_t min_batches = env_min ? (uint64_t)strtoull(env_min, nullptr, 10) : (uint64_t)kCarrierMinBatches;
-    bool carrier = !MSQ_NO_CARRIER;
+    // rounds: a wave's counters hold kMaxBatchesPerWave batches, so a slab with more reads than its workgroups can count
+    // takes the reads in `rounds` equal ranges, one merged launch (+ folds) per range
+    uint64_t rounds = 1;
     size_t need = 0;
     for (int sl = 0; sl < n_slabs; ++sl) {
         if (!share[sl]) continue;
-        const msq_packed_reads* R = sets[sl];
-        const uint64_t n_batches = (R->n_reads + kRows - 1) / kRows;
-        // too few batches to fill the slab's waves, or more reads than its waves' counters hold: one launch per slab
-        if (n_batches < (uint64_t)share[sl] * w || R->n_reads > (uint64_t)share[sl] * w * kMaxBatchesPerWave * kRows) return MSQ_OK;
-        carrier = carrier && n_batches >= min_batches * w * share[sl];
+        const uint64_t cap = (uint64_t)share[sl] * w * kMaxBatchesPerWave * kRows;
+        rounds = std::max<uint64_t>(rounds, (sets[sl]->n_reads + cap - 1) / cap);
         need += (size_t)share[sl] * (NC + 4) * std::min(Gslab, Gtot - sl * Gslab) * 32 * 4;
+    }
+    bool carrier = !MSQ_NO_CARRIER;
+    for (int sl = 0; sl < n_slabs; ++sl) {
+        if (!share[sl]) continue;
+        const uint64_t n_batches = (sets[sl]->n_reads + kRows - 1) / kRows / rounds;  // of the shortest round
+        if (n_batches < (uint64_t)share[sl] * w) return MSQ_OK;  // too few batches to fill the slab's waves: one launch per slab
+        carrier = carrier && n_batches >= min_batches * w * share[sl];
     }
     void* scratch_base = fixed_partials;
     if (fixed_partials) {
@@ -1629,40 +1635,45 @@ static int stream_launch_merged(msq_ctx* ctx, const msq_packed_reads* const* set
     a.codon = d_codon;
     a.err = ctx->d_err;
     for (int k = 0; k < 4; ++k) a.thr[k] = -1;
-    uint32_t wg_first = 0;
-    char* part = static_cast<char*>(scratch_base);
-    for (int sl = 0; sl < n_slabs; ++sl) {
-        if (!share[sl]) continue;
-        const msq_packed_reads* R = sets[sl];
-        SlabDesc& d = a.slabs[a.n_merged++];
-        d.ref_start = R->ref_start;
-        d.group_off = R->group_off;
-        d.bop = reinterpret_cast<const uint4*>(R->bop);
-        d.gcol = idx ? R->gcol : nullptr;
-        d.partials = reinterpret_cast<uint32_t*>(part);
-        d.n_reads = R->n_reads;
-        d.n_batches = (R->n_reads + kRows - 1) / kRows;
-        d.slab0 = sl * Gslab * 32;
-        d.G = std::min(Gslab, Gtot - sl * Gslab);
-        d.wg_first = wg_first;
-        d.wg_count = (uint32_t)share[sl];
-        wg_first += d.wg_count;
-        part += (size_t)share[sl] * (NC + 4) * d.G * 32 * 4;
-    }
     pileup_kernel_fn kern = pick_merged_kernel(passes, many_n, idx);
-    msq_timing_mark_begin(ctx);
     if (lds > 48 * 1024)
         MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
-    msq_timing_mark_end(ctx);
-    MSQ_HIP(hipGetLastError());
-    for (uint32_t k = 0; k < a.n_merged; ++k) {
-        const SlabDesc& d = a.slabs[k];
-        const int col_blocks = (d.G * 32 + kFoldCols - 1) / kFoldCols;
-        const int slices = std::max(1, std::min((int)d.wg_count / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, d.partials, (int)d.wg_count, NC,
-                           d.G * 32, d.slab0, W, d_nuc, d_codon, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    msq_timing_mark_begin(ctx);
+    for (uint64_t round = 0; round < rounds; ++round) {
+        uint32_t wg_first = 0;
+        char* part = static_cast<char*>(scratch_base);  // the folds of a round have read the partials before the next round writes them (stream order)
+        a.n_merged = 0;
+        for (int sl = 0; sl < n_slabs; ++sl) {
+            if (!share[sl]) continue;
+            const msq_packed_reads* R = sets[sl];
+            const uint64_t all_batches = (R->n_reads + kRows - 1) / kRows;
+            SlabDesc& d = a.slabs[a.n_merged++];
+            d.ref_start = R->ref_start;
+            d.group_off = R->group_off;
+            d.bop = reinterpret_cast<const uint4*>(R->bop);
+            d.gcol = idx ? R->gcol : nullptr;
+            d.partials = reinterpret_cast<uint32_t*>(part);
+            d.read_lo = all_batches * round / rounds * kRows;  // whole batches: a round starts at a multiple of eight reads
+            d.read_hi = std::min<uint64_t>(R->n_reads, all_batches * (round + 1) / rounds * kRows);
+            d.n_batches = (d.read_hi - d.read_lo + kRows - 1) / kRows;
+            d.slab0 = sl * Gslab * 32;
+            d.G = std::min(Gslab, Gtot - sl * Gslab);
+            d.wg_first = wg_first;
+            d.wg_count = (uint32_t)share[sl];
+            wg_first += d.wg_count;
+            part += (size_t)share[sl] * (NC + 4) * d.G * 32 * 4;
+        }
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
+        if (round + 1 == rounds) msq_timing_mark_end(ctx);
         MSQ_HIP(hipGetLastError());
+        for (uint32_t k = 0; k < a.n_merged; ++k) {
+            const SlabDesc& d = a.slabs[k];
+            const int col_blocks = (d.G * 32 + kFoldCols - 1) / kFoldCols;
+            const int slices = std::max(1, std::min((int)d.wg_count / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
+            hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, d.partials, (int)d.wg_count,
+                               NC, d.G * 32, d.slab0, W, d_nuc, d_codon, (uint32_t*)nullptr, (uint32_t*)nullptr);
+            MSQ_HIP(hipGetLastError());
+        }
     }
     ++g_merged_launches;
     *handled = true;
