@@ -1360,10 +1360,9 @@ __global__ __launch_bounds__(max_waves_of(NP, PASSES) * 64) void pileup_kernel(S
 // trip for 256 workgroups), the 32 lanes of a column meet in LDS, and what is not zero there leaves as one global
 // atomic per bin.  blockIdx.y slices the workgroups further (more blocks, but as many more global atomics).
 constexpr int kFoldCols = 32, kFoldSubs = 32, kFoldTrip = 8;
-__global__ __launch_bounds__(kFoldCols* kFoldSubs) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
-                                                                             int col0, int W, uint32_t* __restrict__ nuc,
-                                                                             uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
-                                                                             uint32_t* __restrict__ dev_codon)
+__device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols, int col0, int W,
+                                              uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
+                                              uint32_t* __restrict__ dev_codon)
 {
     constexpr int kCodStride = 65, kNucStride = 7;  // odd strides: the lanes of a wave are columns
     __shared__ uint32_t cod_acc[kFoldCols * kCodStride];
@@ -1457,6 +1456,27 @@ __global__ __launch_bounds__(kFoldCols* kFoldSubs) void fold_partials_kernel(con
         const uint32_t v = nuc_acc[(i / 6) * kNucStride + i % 6];
         if (v) atomicAdd(&nuc[i], v);
     }
+}
+
+__global__ __launch_bounds__(kFoldCols* kFoldSubs) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
+                                                                             int col0, int W, uint32_t* __restrict__ nuc,
+                                                                             uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
+                                                                             uint32_t* __restrict__ dev_codon)
+{
+    fold_partials(partials, n_wg, NC, cols, col0, W, nuc, codon, dev_nuc, dev_codon);
+}
+
+// the folds of a merged launch as one launch: blockIdx.z = the slab
+struct FoldSlabs {
+    const uint32_t* partials[kMaxMerged];
+    int n_wg[kMaxMerged], cols[kMaxMerged], col0[kMaxMerged];
+};
+__global__ __launch_bounds__(kFoldCols* kFoldSubs) void fold_slabs_kernel(FoldSlabs t, int NC, int W, uint32_t* __restrict__ nuc,
+                                                                          uint32_t* __restrict__ codon)
+{
+    const int sl = blockIdx.z;
+    if ((int)blockIdx.x * kFoldCols >= t.cols[sl]) return;  // the grid is as wide as the widest slab
+    fold_partials(t.partials[sl], t.n_wg[sl], NC, t.cols[sl], t.col0[sl], W, nuc, codon, nullptr, nullptr);
 }
 
 typedef void (*pileup_kernel_fn)(StreamArgs);
@@ -1666,14 +1686,19 @@ static int stream_launch_merged(msq_ctx* ctx, const msq_packed_reads* const* set
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
         if (round + 1 == rounds) msq_timing_mark_end(ctx);
         MSQ_HIP(hipGetLastError());
+        FoldSlabs ft;
+        memset(&ft, 0, sizeof(ft));
+        int col_blocks = 0;
         for (uint32_t k = 0; k < a.n_merged; ++k) {
             const SlabDesc& d = a.slabs[k];
-            const int col_blocks = (d.G * 32 + kFoldCols - 1) / kFoldCols;
-            const int slices = std::max(1, std::min((int)d.wg_count / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
-            hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, d.partials, (int)d.wg_count,
-                               NC, d.G * 32, d.slab0, W, d_nuc, d_codon, (uint32_t*)nullptr, (uint32_t*)nullptr);
-            MSQ_HIP(hipGetLastError());
+            ft.partials[k] = d.partials;
+            ft.n_wg[k] = (int)d.wg_count;
+            ft.cols[k] = d.G * 32;
+            ft.col0[k] = d.slab0;
+            col_blocks = std::max(col_blocks, (d.G * 32 + kFoldCols - 1) / kFoldCols);
         }
+        hipLaunchKernelGGL(fold_slabs_kernel, dim3(col_blocks, 1, a.n_merged), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, ft, NC, W, d_nuc, d_codon);
+        MSQ_HIP(hipGetLastError());
     }
     ++g_merged_launches;
     *handled = true;
