@@ -277,7 +277,8 @@ int msq_pileup_check(msq_ctx* ctx);
  * s_j the row symbol at index pos[k] + j: 0 ' ' (read does not cover the column), 1..4 A C G T, 5 '-', 6 'N',
  * and 7 for an index CodonAt leaves out (i <= 0 or i >= W: the string is shorter there).  Two reads have the same
  * codon strings at every position exactly when their key rows are equal.  pos is a host array; d_keys is device
- * memory, [n_reads * n_pos].  Synchronises. */
+ * memory, [n_reads * n_pos].  Synchronises.  (Sets with the group column index and no QV plane to apply take a
+ * per-(read, position) lookup when the positions are few against the read length; same keys.) */
 int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
                      int32_t W, int32_t n_pos, const int32_t* pos, uint16_t* d_keys);
 

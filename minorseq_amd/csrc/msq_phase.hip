@@ -48,7 +48,98 @@ __global__ __launch_bounds__(256) void phase_codons_kernel(const int32_t* __rest
     if (my_err) atomicOr(err, my_err);
 }
 
+// ---- the gather by LOOKUP: with the group column index a read's symbol at a column is found without building its row.
+// Thread = (read, position); the group that holds reference column c is at or behind group (c - ReferenceStart) / 32 of
+// its read (a group consumes at most 32 columns), usually right there (only inserted bases push it back), and the
+// index says where every group starts.  Touches K groups of a read instead of all of them, knows no column slabs:
+// what pays when the positions are few against the read length (wide windows).  Sets without QV planes in the loop
+// and without exotic symbols only; the symbols are those of the stream kernel's rows.
+__device__ __forceinline__ uint32_t kth_set_bit(uint32_t m, uint32_t k)  // position of the k-th (0-based) set bit; k < popc(m)
+{
+    uint32_t pos = 0;
+#pragma unroll
+    for (int w = 16; w >= 1; w >>= 1) {
+        const uint32_t low = __popc(m & ((1u << w) - 1u));
+        if (k >= low) {
+            k -= low;
+            m >>= w;
+            pos += w;
+        }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(256) void phase_lookup_kernel(const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ group_off,
+                                                           const uint4* __restrict__ bop, const uint32_t* __restrict__ gcol,
+                                                           uint64_t n_reads, uint32_t normalized, int32_t win_begin0, int32_t W, int32_t n_pos,
+                                                           const int32_t* __restrict__ pos, uint16_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ err)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t r = t / (uint32_t)n_pos;
+    if (r >= n_reads) return;
+    const int k = (int)(t - r * (uint32_t)n_pos);
+    const int64_t rs = ref_start[r];
+    const uint64_t g0 = group_off[r], g1 = group_off[r + 1];
+    const int64_t ng = (int64_t)(g1 - g0);
+    auto col_of = [&](int64_t i) -> int64_t { return (int64_t)(gcol[g0 + i] & 0x1fffffffu) - 1; };
+    if (k == 0 && ng > 0) {  // a read that leaves the window: assert(pos >= 0) / the write past the row, MSA.cpp:149
+        const int64_t end = col_of(ng - 1) + __popc(~bop[g1 - 1].w);
+        if (rs < win_begin0 || end > (int64_t)win_begin0 + W) atomicOr(err, (uint32_t)DEVERR_WINDOW);
+    }
+    const int p = pos[k];
+    uint32_t key = 0;
+    int64_t gi = -1;   // group of the previous column, its first column and planes: the next column is mostly in it too
+    int64_t gc = 0;
+    uint4 w = make_uint4(0, 0, 0, ~0u);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {  // MSARow::CodonAt: indices with i > 0 && i < length only (MSA.cpp:188-195)
+        const int i = p + j;
+        uint32_t sym = 7u;
+        if (i > 0 && i < W) {
+            sym = 0u;  // ' ': the read does not reach the column
+            const int64_t c = (int64_t)win_begin0 + i;
+            if (c >= rs && ng > 0) {
+                int64_t g = gi >= 0 ? gi : (c - rs) >> 5;
+                if (g > ng - 1) g = ng - 1;
+                // forward to the last group that starts at or before c: a few steps, then by bisection
+                int steps = 0;
+                while (g + 1 < ng && col_of(g + 1) <= c && steps < 4) {
+                    ++g;
+                    ++steps;
+                }
+                if (steps == 4 && g + 1 < ng && col_of(g + 1) <= c) {
+                    int64_t lo = g + 1, hi = ng - 1;  // col_of(lo) <= c
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi + 1) >> 1;
+                        if (col_of(mid) <= c) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    g = lo;
+                }
+                if (g != gi) {
+                    gi = g;
+                    gc = col_of(g);
+                    w = bop[g0 + g];
+                }
+                const uint32_t cons = ~w.w;  // ops 0, 1 consume a column
+                const int64_t kin = c - gc;
+                if (kin >= 0 && kin < __popc(cons)) {
+                    const uint32_t b = normalized ? (uint32_t)kin : kth_set_bit(cons, (uint32_t)kin);
+                    const uint32_t xb = (w.x >> b) & 1u, yb = (w.y >> b) & 1u, zb = (w.z >> b) & 1u;
+                    sym = zb ? 5u + xb : 1u + (xb | (yb << 1));  // op 1: '-' or a literal 'N'; op 0: the nucleotide
+                }
+            }
+        }
+        key |= sym << (3 * j);
+    }
+    keys[t] = (uint16_t)key;
+}
+
 }  // namespace
+
+static int g_phase_lookups = 0;  // calls that took the lookup kernel (tests ask which path ran)
+extern "C" int msq_debug_phase_lookups(void) { return g_phase_lookups; }
 
 extern "C" int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
                                 int32_t W, int32_t n_pos, const int32_t* pos, uint16_t* d_keys)
@@ -59,6 +150,33 @@ extern "C" int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, c
     if (!pos || !d_keys) return msq_fail(MSQ_ERR_ARG, "msq_phase_codons: NULL positions / keys");
     if (int rc = msq_validate_reads(d_reads, thr, "msq_phase_codons")) return rc;
     MSQ_HIP(hipSetDevice(ctx->device));
+    {  // few positions against the read length, a set with the column index and no QV plane to apply: the lookup
+        const uint8_t* planes[4] = {d_reads->qual, d_reads->delqv, d_reads->subqv, d_reads->insqv};
+        const int32_t thrs[4] = {thr->qual, thr->del, thr->sub, thr->ins};
+        bool qv = false;
+        for (int k = 0; k < 4; ++k) qv = qv || (thrs[k] >= 0 && planes[k]);
+        // measured (tools/phase_ab.sh, picoseconds per read): the streaming gather 3.8 per group and column slab + 2.6 per
+        // position; the lookup 2 per group (the read's index lines, its window check) + 11 per position
+        const double groups_per_read = (double)d_reads->n_groups / (double)d_reads->n_reads;
+        const int n_slabs = ((W + 31) / 32 + 127) / 128;
+        const char* force = getenv("MSQ_PHASE_LOOKUP");  // 1: always (when applicable), 0: never
+        const bool pays = force ? force[0] == '1' : 8.4 * (double)n_pos < groups_per_read * (3.8 * n_slabs - 2.0);
+        if (d_reads->gcol && !qv && !(d_reads->flags & MSQ_READS_HAS_EXOTIC) && d_reads->n_groups && pays && win_begin0 >= 0 &&
+            (int64_t)win_begin0 + W < 0x1fffff00 && (uint64_t)d_reads->n_reads * (uint64_t)n_pos < (1ull << 38)) {
+            void* s = nullptr;
+            int rc = msq_scratch(ctx, (size_t)n_pos * sizeof(int32_t), &s);
+            if (rc != MSQ_OK) return rc;
+            MSQ_HIP(hipMemcpyAsync(s, pos, (size_t)n_pos * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+            const uint64_t threads = d_reads->n_reads * (uint64_t)n_pos;
+            hipLaunchKernelGGL(phase_lookup_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, d_reads->ref_start,
+                               d_reads->group_off, reinterpret_cast<const uint4*>(d_reads->bop), d_reads->gcol, d_reads->n_reads,
+                               (d_reads->flags & MSQ_READS_NORMALIZED) ? 1u : 0u, win_begin0, W, n_pos, (const int32_t*)s, d_keys, ctx->d_err);
+            MSQ_HIP(hipGetLastError());
+            MSQ_HIP(hipStreamSynchronize(ctx->stream));  // the positions live in the context's scratch
+            ++g_phase_lookups;
+            return MSQ_OK;
+        }
+    }
     {  // fast path: phase 1 of the streaming pileup kernel + a gather from its LDS rows
         bool handled = false;
         int rc = msq_phase_stream_launch(ctx, *d_reads, *thr, win_begin0, W, n_pos, pos, d_keys, &handled);
