@@ -29,8 +29,40 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x)
     return x;
 }
 
-// one wave per 64 reads: lane k walks the rows' k-th, k + 64-th ... keys (coalesced over the row), the lanes' partial
-// hashes are position-dependent, so that their sum does not depend on the order they are added in
+// Short rows (K <= kStagedKeys): one block per 256 reads -- their key rows are one contiguous piece of memory, read
+// coalesced into LDS (row stride an odd number of dwords: no bank conflicts), then one thread per row.
+constexpr int kStagedKeys = 62;
+__global__ __launch_bounds__(256) void hash_rows_staged_kernel(const uint16_t* __restrict__ keys, uint64_t n, int K, uint64_t* __restrict__ hash,
+                                                               uint32_t* __restrict__ idx)
+{
+    __shared__ uint16_t stage[256 * (kStagedKeys + 2)];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t r0 = (uint64_t)blockIdx.x * 256;
+    const uint32_t rows = (uint32_t)min((uint64_t)256, n - r0);
+    const uint32_t Ku = (uint32_t)K, S = (((Ku + 1u) >> 1) | 1u) * 2u;  // u16 per staged row; K >= 1
+    const uint16_t* base = keys + r0 * (uint64_t)K;
+    const uint32_t total = rows * Ku, dr = 256u / Ku, dk = 256u % Ku;
+    uint32_t r = tid / Ku, k = tid % Ku;  // element tid + 256 j = key k of row r
+    for (uint32_t i = tid; i < total; i += 256) {
+        stage[r * S + k] = base[i];
+        r += dr;
+        k += dk;
+        if (k >= Ku) {
+            k -= Ku;
+            ++r;
+        }
+    }
+    __syncthreads();
+    if (tid < rows) {
+        uint64_t h = 0;
+        for (uint32_t j = 0; j < Ku; ++j) h += mix64(((uint64_t)(j + 1) << 16) | stage[tid * S + j]);
+        hash[r0 + tid] = mix64(h);
+        idx[r0 + tid] = (uint32_t)(r0 + tid);
+    }
+}
+
+// Longer rows: one wave per 64 reads, lane k walks the rows' k-th, k + 64-th ... keys (coalesced over the row); the
+// lanes' partial hashes are position-dependent, so that their sum does not depend on the order they are added in
 __global__ __launch_bounds__(256) void hash_rows_kernel(const uint16_t* __restrict__ keys, uint64_t n, int K, uint64_t* __restrict__ hash,
                                                         uint32_t* __restrict__ idx)
 {
@@ -122,7 +154,7 @@ extern "C" int msq_phase_cluster(msq_ctx* ctx, const uint16_t* d_keys, uint64_t 
 {
     if (!ctx || !n_clusters) return msq_fail(MSQ_ERR_ARG, "msq_phase_cluster: NULL argument");
     *n_clusters = 0;
-    if (n_pos < 0) return msq_fail(MSQ_ERR_ARG, "msq_phase_cluster: negative row length");
+    if (n_pos < 0 || n_pos > (1 << 20)) return msq_fail(MSQ_ERR_ARG, "msq_phase_cluster: row length %d out of range (0 .. 2^20)", n_pos);
     if (n_reads == 0) return MSQ_OK;
     if (n_reads > 0x7fffffffull) return msq_fail(MSQ_ERR_ARG, "msq_phase_cluster: too many reads (hipCUB counts in int)");
     if ((n_pos > 0 && !d_keys) || !d_cluster_of || !d_first_read || !d_count) return msq_fail(MSQ_ERR_ARG, "msq_phase_cluster: NULL device buffer");
@@ -165,7 +197,10 @@ extern "C" int msq_phase_cluster(msq_ctx* ctx, const uint16_t* d_keys, uint64_t 
     size_t tb = tmp_bytes;
 
     MSQ_HIP(hipMemsetAsync(collision, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(hash_rows_kernel, dim3(blocks_for(((n + 63) / 64) * 64)), dim3(256), 0, ctx->stream, d_keys, n, K, hash, idx);
+    if (K >= 1 && K <= kStagedKeys)
+        hipLaunchKernelGGL(hash_rows_staged_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, d_keys, n, K, hash, idx);
+    else
+        hipLaunchKernelGGL(hash_rows_kernel, dim3(blocks_for(((n + 63) / 64) * 64)), dim3(256), 0, ctx->stream, d_keys, n, K, hash, idx);
     MSQ_HIP(hipGetLastError());
     MSQ_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, (const uint64_t*)hash, hash_s, (const uint32_t*)idx, idx_s, (int)n, 0, 64, ctx->stream));
     hipLaunchKernelGGL(segment_flags_kernel, dim3(blocks_for(n)), dim3(256), 0, ctx->stream, d_keys, K, (const uint64_t*)hash_s,
