@@ -43,6 +43,8 @@ def both_ways(monkeypatch, run, expect_merged=True):
     ("hiv_mix_200k", 40000, {}),
     ("hiv_mix_200k", 30000, dict(ins=0.02, dele=0.03, sub=0.01, n_minors=1, minor_frac=0.2, minor_codons=200)),
     ("amp20k_10m", 24000, {}),
+    ("hiv_mix_200k", 36000, dict(jitter_frac=0.6, max_jitter=3000, ins=0.01)),  # ragged reads: the slabs hold unequal shares
+    ("amp20k_10m", 30000, dict(jitter_frac=0.9, max_jitter=9000, dele=0.02, seed=7)),
     ("amp20k_10m", 450000, {}),  # more reads than a slab's share of the waves can count in one launch: two rounds
 ])
 def test_one_set_and_partition(ctx, monkeypatch, name, n, kw):
