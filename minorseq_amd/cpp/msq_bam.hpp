@@ -473,33 +473,68 @@ private:
             if (l_name > data.size() || off + 4 + l_name + 4 > data.size()) throw std::runtime_error("truncated BAM header");
             off += 4 + l_name + 4;
         }
-        // pass 1 (cheap, sequential): record offsets, filters, idx of the kept ones
+        // pass 1a (sequential, one length word per record): where the records are.  A record that runs past the end of
+        // the stream is reported after every malformed record before it, as one pass in file order would
+        std::vector<size_t> bodies;
+        bool truncated = false;
         while (off + 4 <= data.size()) {
             const size_t block_size = U32(&data[off]);
-            const uint8_t* rec = &data[off + 4];
             const size_t body = off + 4;
             off += 4 + block_size;
-            if (off > data.size() || block_size < 32) throw std::runtime_error("truncated BAM record");
-            ++L.n_records;
-            const size_t l_read_name = rec[8];
-            const size_t n_cigar = U16(rec + 12);
-            const uint16_t flag = U16(rec + 14);
-            const size_t l_seq = U32(rec + 16);
-            if (32 + l_read_name + 4 * n_cigar + (l_seq + 1) / 2 + l_seq > block_size) throw std::runtime_error("malformed BAM record");
-            if (flag & 0x800) continue;  // IsSupplementaryAlignment (BamUtils.cpp:69)
-            if (flag & 0x100) continue;  // !IsPrimaryAlignment (BamUtils.cpp:70)
-            if (flag & 0x4) continue;    // unmapped: no reference interval to overlap
-            const uint8_t* cigar = rec + 32 + l_read_name;
-            int64_t ref_len = 0;
-            for (size_t k = 0; k < n_cigar; ++k) {
-                const uint32_t c = U32(cigar + 4 * k);
-                const int op = c & 15;
-                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+            if (off > data.size() || block_size < 32) {
+                truncated = true;
+                break;
             }
-            const int64_t ref_start = I32(rec + 4), ref_end = ref_start + ref_len;
-            if (!(ref_start < regionEnd && ref_end > regionStart)) continue;  // BamUtils.cpp:71
-            L.kept.push_back({body, block_size, ref_start, ref_end});
+            bodies.push_back(body);
         }
+        L.n_records = bodies.size();
+        // pass 1b (threads over record ranges): the record's own consistency, the filters, the reference interval
+        const size_t nrec = bodies.size();
+        std::vector<Kept> all(nrec);
+        std::vector<uint8_t> keep(nrec, 0);
+        const unsigned workers = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, nrec / 4096 + 1));
+        std::vector<size_t> bad(workers, SIZE_MAX);  // first malformed record of each range
+        auto scan = [&](unsigned w) {
+            for (size_t i = nrec * w / workers; i < nrec * (w + 1) / workers; ++i) {
+                const size_t body = bodies[i];
+                const size_t block_size = U32(&data[body - 4]);
+                const uint8_t* rec = &data[body];
+                const size_t l_read_name = rec[8];
+                const size_t n_cigar = U16(rec + 12);
+                const uint16_t flag = U16(rec + 14);
+                const size_t l_seq = U32(rec + 16);
+                if (32 + l_read_name + 4 * n_cigar + (l_seq + 1) / 2 + l_seq > block_size) {
+                    bad[w] = i;
+                    return;
+                }
+                if (flag & 0x800) continue;  // IsSupplementaryAlignment (BamUtils.cpp:69)
+                if (flag & 0x100) continue;  // !IsPrimaryAlignment (BamUtils.cpp:70)
+                if (flag & 0x4) continue;    // unmapped: no reference interval to overlap
+                const uint8_t* cigar = rec + 32 + l_read_name;
+                int64_t ref_len = 0;
+                for (size_t k = 0; k < n_cigar; ++k) {
+                    const uint32_t c = U32(cigar + 4 * k);
+                    const int op = c & 15;
+                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += c >> 4;
+                }
+                const int64_t ref_start = I32(rec + 4), ref_end = ref_start + ref_len;
+                if (!(ref_start < regionEnd && ref_end > regionStart)) continue;  // BamUtils.cpp:71
+                all[i] = {body, block_size, ref_start, ref_end};
+                keep[i] = 1;
+            }
+        };
+        if (workers == 1) {
+            scan(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned w = 0; w < workers; ++w) pool.emplace_back(scan, w);
+            for (auto& th : pool) th.join();
+        }
+        for (unsigned w = 0; w < workers; ++w)
+            if (bad[w] != SIZE_MAX) throw std::runtime_error("malformed BAM record");
+        if (truncated) throw std::runtime_error("truncated BAM record");
+        for (size_t i = 0; i < nrec; ++i)
+            if (keep[i]) L.kept.push_back(all[i]);
         const auto t3 = Clock::now();
         L.t_read = secs(t0, t1);
         L.t_inflate = secs(t1, t2);
