@@ -435,12 +435,17 @@ def main():
     pcie = None
     if a.h2d_steps > 0 and world == 1:  # the boundary handing over host buffers: packed reads cross PCIe every step
         dr = run.dr
-        host = {f: t.cpu().pin_memory() for f, t in dr.t.items() if t is not None}
+        # what crosses: the tables, the bit planes and the QV planes this run's thresholds read -- not the planes
+        # nobody looks at, and not the column index, which is derived data: rebuilt on the device after every copy
+        need = {"ref_start", "ref_end", "group_off", "bop"} | ({"qual"} if a.qualqv >= 0 else set()) | ({"subqv"} if a.rich else set())
+        host = {f: t.cpu().pin_memory() for f, t in dr.t.items() if t is not None and f in need}
         barrier()
         t1 = time.perf_counter()
         for _ in range(a.h2d_steps):
             for f, h in host.items():
                 dr.t[f].copy_(h, non_blocking=True)
+            if dr.t.get("gcol") is not None:
+                run.abi.check(run.L.msq_reads_index(ctx.h, dr.view, dr.t["gcol"].data_ptr()))
             run.step()
         barrier()
         dt1 = (time.perf_counter() - t1) / a.h2d_steps
