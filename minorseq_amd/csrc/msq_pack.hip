@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(const uint64_t* __rest
                                                           uint8_t* __restrict__ q_qual, uint8_t* __restrict__ q_del,
                                                           uint8_t* __restrict__ q_sub, uint8_t* __restrict__ q_ins,
                                                           unsigned long long* __restrict__ err, uint32_t* __restrict__ flags, int plain,
-                                                          int bake, msq_qv_thresholds thr)
+                                                          int bake, msq_qv_thresholds thr, int compact)
 {
     __shared__ uint8_t nib[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, k = lane & 31;
@@ -231,17 +231,26 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(const uint64_t* __rest
     const uint64_t b0 = base_off[lo], len = base_off[lo + 1] - b0;
     const uint64_t i = (gs - group_off[lo]) * 32 + (uint64_t)k;
     const bool has = valid_g && i < len;
-    const uint64_t w = has ? stage[b0 - chunk_base0 + i] : 0;  // {Cigar, Nucleotide, HasQualQV, HasRichQVs, QualQV, DelQV, SubQV, InsQV}
+    // compact staging (the baked packer): one byte per base, translated and thresholded on the host (compact_record)
+    const uint8_t c8 = (has && compact) ? reinterpret_cast<const uint8_t*>(stage)[b0 - chunk_base0 + i] : (uint8_t)0;
+    const uint64_t w = (has && !compact) ? stage[b0 - chunk_base0 + i] : 0;  // {Cigar, Nucleotide, HasQualQV, HasRichQVs, QualQV, DelQV, SubQV, InsQV}
     unsigned op = 3, code = 0;
     bool exotic = false, ins_exotic = false;
-    if (has && !encode_base((char)(w & 0xff), (char)((w >> 8) & 0xff), &op, &code, &exotic, &ins_exotic)) {
+    if (compact) {
+        if (has) {
+            code = c8 & 3u;
+            op = (c8 >> 2) & 3u;
+            exotic = (c8 & 16u) != 0;
+            ins_exotic = (c8 & 32u) != 0;
+        }
+    } else if (has && !encode_base((char)(w & 0xff), (char)((w >> 8) & 0xff), &op, &code, &exotic, &ins_exotic)) {
         atomicMin(err, (unsigned long long)(((b0 + i) << 8) | (w & 0xff)));  // the first one in read order is reported
         op = 3;
         code = 0;
     }
     if (exotic) atomicOr(flags, MSQ_READS_HAS_EXOTIC);
     if (ins_exotic) atomicOr(flags, MSQ_READS_INS_EXOTIC);
-    if (bake && has) {
+    if (bake && has && !compact) {
         // the thresholds applied while packing (what msq_reads_bake_qv does to a packed set): a '=' / 'X' base -- op 0,
         // or one of the exotic match bases under op 1, codes 2 and 3 -- that misses a threshold becomes the literal 'N'
         // MSAByRow::AddRead writes for it (src/MSA.cpp:163-166); an absent QV passes (ArrayRead.inl:72-87)
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(const uint64_t* __rest
     const unsigned v = nib[wave][lane];
     const uint64_t p0 = __ballot(v & 1u), p1 = __ballot(v & 2u), p2 = __ballot(v & 4u), p3 = __ballot(v & 8u);
     if (k == 0 && valid_g) bop[g] = make_uint4((uint32_t)(p0 >> (32 * h)), (uint32_t)(p1 >> (32 * h)), (uint32_t)(p2 >> (32 * h)), (uint32_t)(p3 >> (32 * h)));
-    if (has) {  // an absent QV always passes (ArrayRead.inl:72-87): 255 passes every threshold
+    if (has && !compact) {  // an absent QV always passes (ArrayRead.inl:72-87): 255 passes every threshold
         const uint64_t at = g * 32 + (uint64_t)MSQ_QV_BYTE(slot);
         const bool hq = (w >> 16) & 0xff, hr = (w >> 24) & 0xff;
         if (q_qual) q_qual[at] = hq ? (uint8_t)(w >> 32) : (uint8_t)255;
@@ -290,6 +299,57 @@ static uint64_t copy_or(uint64_t* dst, const msq_array_base* src, int64_t n)
     return acc;
 }
 
+// The baked packer's staging: one byte per base instead of the 8-byte record.  With the thresholds known while packing,
+// everything the kernel would derive from a record is derived here, where the record is read anyway -- translation
+// (encode_base, through a table over (Cigar, Nucleotide)), the threshold test (ArrayRead.inl:67-87) and its 'N' -- and
+// an eighth of the bytes crosses PCIe: byte = code | op << 2 | exotic << 4 | inserted-exotic << 5; 0x80 = unknown cigar.
+struct CompactTable {
+    uint8_t t[65536];
+    CompactTable()
+    {
+        for (unsigned v = 0; v < 65536; ++v) {
+            unsigned op = 3, code = 0;
+            bool exotic = false, ins_exotic = false;
+            t[v] = encode_base((char)(v & 0xff), (char)(v >> 8), &op, &code, &exotic, &ins_exotic)
+                       ? (uint8_t)(code | (op << 2) | (exotic ? 16u : 0u) | (ins_exotic ? 32u : 0u))
+                       : (uint8_t)0x80;
+        }
+    }
+};
+static const CompactTable& compact_table()
+{
+    static const CompactTable table;
+    return table;
+}
+// n records -> n bytes; returns the OR of the records; *first_bad = index of the first record with an unknown cigar (or n)
+static uint64_t compact_records(uint8_t* dst, const void* src, int64_t n, const msq_qv_thresholds& thr, int64_t* first_bad)
+{
+    const uint8_t* T = compact_table().t;
+    const bool any_thr = thr.qual >= 0 || thr.del >= 0 || thr.sub >= 0 || thr.ins >= 0;
+    uint64_t acc = 0;
+    int64_t bad = n;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t w;
+        std::memcpy(&w, static_cast<const char*>(src) + 8 * i, 8);  // the caller's records need not be 8-byte aligned
+        acc |= w;
+        uint8_t c = T[w & 0xffff];
+        if (c & 0x80) {
+            if (bad == n) bad = i;
+            c = 12;  // op 3, code 0: what the kernel writes for it
+        } else if (any_thr) {
+            const bool hq = (w >> 16) & 0xff, hr = (w >> 24) & 0xff;
+            const int qq = (int)((w >> 32) & 0xff), qd = (int)((w >> 40) & 0xff), qs = (int)((w >> 48) & 0xff), qi = (int)((w >> 56) & 0xff);
+            const bool pass = (thr.qual < 0 || !hq || qq >= thr.qual) && (thr.del < 0 || !hr || qd >= thr.del) &&
+                              (thr.sub < 0 || !hr || qs >= thr.sub) && (thr.ins < 0 || !hr || qi >= thr.ins);
+            const unsigned op = (c >> 2) & 3u, code = c & 3u;
+            if (!pass && (op == 0 || (op == 1 && code >= 2))) c = (uint8_t)((c & 0x30) | 5);  // op 1, code 1: the literal 'N' (MSA.cpp:163-166)
+        }
+        dst[i] = c;
+    }
+    *first_bad = bad;
+    return acc;
+}
+
 static void free_packed_dev(msq_packed_dev* d)
 {
     for (int j = 0; j < 9; ++j)
@@ -306,6 +366,32 @@ static uint64_t stage_read(uint64_t* dst, uint64_t r, const msq_array_base* cons
     fill(user, r, reinterpret_cast<msq_array_base*>(dst));
     uint64_t acc = 0;
     for (int64_t i = 0; i < n_bases[r]; ++i) acc |= dst[i];
+    return acc;
+}
+
+// the same into compact staging; `tmp` (the callback's records) holds the longest read; bad_key: (base index << 8 | char)
+// of the first unknown cigar this thread met, in read order
+static uint64_t stage_read_compact(uint8_t* dst, uint64_t r, uint64_t base0, const msq_array_base* const* bases, const int64_t* n_bases,
+                                   msq_fill_read_fn fill, void* user, std::vector<uint64_t>& tmp, const msq_qv_thresholds& thr,
+                                   unsigned long long* bad_key)
+{
+    const int64_t n = n_bases[r];
+    const void* src;
+    if (fill) {
+        if ((int64_t)tmp.size() < n) tmp.resize((size_t)n);
+        fill(user, r, reinterpret_cast<msq_array_base*>(tmp.data()));
+        src = tmp.data();
+    } else {
+        src = bases[r];
+    }
+    int64_t bad = n;
+    const uint64_t acc = compact_records(dst, src, n, thr, &bad);
+    if (bad < n) {
+        uint64_t w;
+        std::memcpy(&w, static_cast<const char*>(src) + 8 * bad, 8);
+        const unsigned long long key = ((unsigned long long)(base0 + (uint64_t)bad) << 8) | (w & 0xff);
+        if (key < *bad_key) *bad_key = key;
+    }
     return acc;
 }
 
@@ -399,6 +485,13 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
         if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "base offsets", e);
     }
 
+    // the baked packer over the caller's own records stages one translated byte per base (compact_records: 0.040 instead
+    // of 0.056 s per 10^5 reads through the front); MSQ_PACK_WIDE_STAGING=1 keeps the records.  Records a callback writes
+    // (the BAM front) go into the pinned buffer as they are: decoding them is what that path waits for, a second pass
+    // over them wins nothing (measured)
+    const char* wide = getenv("MSQ_PACK_WIDE_STAGING");
+    const bool compact = bake_thr != nullptr && !fill && !(wide && wide[0] == '1');
+    unsigned long long host_bad = ~0ull;  // first unknown cigar seen while compacting: (base index << 8) | char
     uint64_t r0 = 0;
     for (int chunk = 0; r0 < n_reads; ++chunk) {
         uint64_t r1 = r0 + 1;  // at least one read; cap >= the longest read
@@ -410,12 +503,30 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
             if (e != hipSuccess) return fail(MSQ_ERR_HIP, "hipEventSynchronize", e);
         }
         uint64_t* hs = (uint64_t*)ctx->h_stage[b];
+        uint8_t* hs8 = (uint8_t*)ctx->h_stage[b];
         uint64_t any = 0;
         const unsigned workers = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_thr, cb >> 17));  // >= 1 MB each
+        // one read into this chunk's staging, in the mode of the call
+        auto stage_one = [&](uint64_t r, std::vector<uint64_t>& tmp, unsigned long long* bad) -> uint64_t {
+            const uint64_t at = base_off[r] - base_off[r0];
+            return compact ? stage_read_compact(hs8 + at, r, base_off[r], bases, n_bases, fill, user, tmp, thr, bad)
+                           : stage_read(hs + at, r, bases, n_bases, fill, user);
+        };
         if (workers == 1) {
-            for (uint64_t r = r0; r < r1; ++r) any |= stage_read(hs + (base_off[r] - base_off[r0]), r, bases, n_bases, fill, user);
+            try {
+                std::vector<uint64_t> tmp;
+                for (uint64_t r = r0; r < r1; ++r) any |= stage_one(r, tmp, &host_bad);
+            } catch (const std::bad_alloc&) {
+                (void)hipStreamSynchronize(ctx->stream);
+                if (d_base_off) (void)hipFree(d_base_off);
+                free_packed_dev(d);
+                return msq_fail(MSQ_ERR_NOMEM, "msq_pack_reads_device: out of memory");
+            }
         } else {
             uint64_t ors[64] = {0};
+            unsigned long long bads[64];
+            bool oom[64] = {false};
+            for (unsigned t = 0; t < 64; ++t) bads[t] = ~0ull;
             std::vector<std::thread> pool;
             bool spawned = true;
             try {  // no C++ exception may leave through the C ABI, and no joinable thread may be destroyed
@@ -427,7 +538,12 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
                     const uint64_t rb = t + 1 == workers ? r1 : std::lower_bound(base_off.begin() + r0, base_off.begin() + r1, hi_b) - base_off.begin();
                     pool.emplace_back([&, t, ra, rb] {
                         uint64_t acc = 0;
-                        for (uint64_t r = ra; r < rb; ++r) acc |= stage_read(hs + (base_off[r] - base_off[r0]), r, bases, n_bases, fill, user);
+                        try {
+                            std::vector<uint64_t> tmp;
+                            for (uint64_t r = ra; r < rb; ++r) acc |= stage_one(r, tmp, &bads[t]);
+                        } catch (const std::bad_alloc&) {
+                            oom[t] = true;
+                        }
                         ors[t] = acc;
                     });
                 }
@@ -441,7 +557,18 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
                 free_packed_dev(d);
                 return msq_fail(MSQ_ERR_NOMEM, "msq_pack_reads_device: cannot start %u staging threads", workers);
             }
-            for (unsigned t = 0; t < workers; ++t) any |= ors[t];
+            bool any_oom = false;
+            for (unsigned t = 0; t < workers; ++t) {
+                any |= ors[t];
+                host_bad = std::min(host_bad, bads[t]);
+                any_oom = any_oom || oom[t];
+            }
+            if (any_oom) {
+                (void)hipStreamSynchronize(ctx->stream);
+                if (d_base_off) (void)hipFree(d_base_off);
+                free_packed_dev(d);
+                return msq_fail(MSQ_ERR_NOMEM, "msq_pack_reads_device: out of memory");
+            }
         }
         any_all |= any;
         // QV planes appear with the first chunk that carries the QV; every base before it lacked it -> 255.  With the
@@ -456,7 +583,7 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
                 if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "QV plane", e);
             }
         if (cb) {
-            hipError_t e = hipMemcpyAsync(d_stage, hs, cb * 8, hipMemcpyHostToDevice, ctx->stream);
+            hipError_t e = hipMemcpyAsync(d_stage, hs, compact ? cb : cb * 8, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipEventRecord(ctx->stage_done[b], ctx->stream);
             if (e != hipSuccess) return fail(MSQ_ERR_HIP, "staging copy", e);
             const uint64_t g0 = group_off[r0], g1 = group_off[r1];
@@ -464,7 +591,7 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
             hipLaunchKernelGGL(pack_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_stage, base_off[r0],
                                (const uint64_t*)d_base_off, (const uint64_t*)d->ptrs[2], r0, r1, g0, g1, (uint4*)d->ptrs[3],
                                (uint8_t*)d->ptrs[4], (uint8_t*)d->ptrs[5], (uint8_t*)d->ptrs[6], (uint8_t*)d->ptrs[7], d_errword, d_flags, plain,
-                               bake_thr ? 1 : 0, thr);
+                               bake_thr ? 1 : 0, thr, compact ? 1 : 0);
             e = hipGetLastError();
             if (e != hipSuccess) return fail(MSQ_ERR_HIP, "pack kernel", e);
         } else {
@@ -481,6 +608,7 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
     }
     (void)hipFree(d_base_off);
     d_base_off = nullptr;
+    res[0] = std::min<uint64_t>(res[0], host_bad);
     if (res[0] != ~0ull) {
         free_packed_dev(d);
         // std::runtime_error("Unexpected cigar " + std::to_string(b.Cigar)), src/MSA.cpp:182

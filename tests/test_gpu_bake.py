@@ -66,7 +66,7 @@ def test_baked_counts_equal_thresholded_counts(ctx, name, plain):
 
 @pytest.mark.parametrize("plain", [False, True])
 @pytest.mark.parametrize("name", sorted(EDGE) + ["random_rich", "random_qual", "wide_rich", "high_thr", "some_absent"])
-def test_packer_applies_thresholds_like_pack_then_bake(ctx, name, plain):
+def test_packer_applies_thresholds_like_pack_then_bake(ctx, monkeypatch, name, plain):
     """msq_pack_reads_device_baked == msq_pack_reads_device + msq_reads_bake_qv, byte for byte: tables, bit planes,
     flags, no QV planes -- with one chunk and with many, with QVs present on some bases only."""
     has_qual = has_rich = None
@@ -81,7 +81,12 @@ def test_packer_applies_thresholds_like_pack_then_bake(ctx, name, plain):
     src = device.upload(device.pack_device(ctx, reads, has_qual=has_qual, has_rich=has_rich, plain=plain), ctx.device)
     want_set = device.bake_qv(ctx, src, q)
     want = want_set.download()
-    for chunk_bases, threads in ((0, 0), (700, 3)):
+    for chunk_bases, threads, wide in ((0, 0, False), (700, 3, False), (0, 0, True), (900, 2, True)):
+        # wide: the 8-byte records staged as they are and translated on the device; else one translated byte per base
+        if wide:
+            monkeypatch.setenv("MSQ_PACK_WIDE_STAGING", "1")
+        else:
+            monkeypatch.delenv("MSQ_PACK_WIDE_STAGING", raising=False)
         got = device.pack_device(ctx, reads, has_qual=has_qual, has_rich=has_rich, plain=plain, thr=q, chunk_bases=chunk_bases, threads=threads)
         assert got["flags"] == want["flags"], (got["flags"], want["flags"])
         assert got["n_groups"] == want["n_groups"]
@@ -90,6 +95,7 @@ def test_packer_applies_thresholds_like_pack_then_bake(ctx, name, plain):
         for f in ("ref_start", "ref_end", "group_off", "bop"):
             assert (np.asarray(got[f]) == np.asarray(want[f])).all(), f
     want_set.close()
+    monkeypatch.delenv("MSQ_PACK_WIDE_STAGING", raising=False)
     with pytest.raises(abi.MsqError) as err:
         device.pack_device(ctx, reads, thr=abi.QvThresholds.make(qual=256))
     assert err.value.code == abi.MSQ_ERR_ARG

@@ -109,6 +109,10 @@ def test_unexpected_cigar(ctx):
         with pytest.raises(abi.MsqError) as e:
             device.pack_device(ctx, reads, chunk_bases=chunk)
         assert e.value.code == abi.MSQ_ERR_CIGAR and "Unexpected cigar %d" % ord("M") in str(e.value)
+        for threads in (1, 5):  # the packer that applies thresholds translates on the host (compact staging): the same report
+            with pytest.raises(abi.MsqError) as eb:
+                device.pack_device(ctx, reads, chunk_bases=chunk, threads=threads, thr=abi.QvThresholds.make(qual=20))
+            assert str(eb.value) == str(e.value)
     with pytest.raises(abi.MsqError) as e2:
         device.pack_host(reads)
     assert str(e2.value) == str(e.value)
