@@ -434,7 +434,13 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
     const uint64_t total_bases = base_off[n_reads], n_groups = group_off[n_reads];
     uint64_t cap = chunk_bases > 0 ? (uint64_t)chunk_bases : (uint64_t)32 << 20;  // records per chunk (256 MB)
     cap = std::max<uint64_t>(std::min(cap, total_bases), (uint64_t)longest);
-    const size_t stage_bytes = std::max<size_t>(cap * 8, 64);
+    // the baked packer over the caller's own records stages one translated byte per base (compact_records: 0.040 instead
+    // of 0.056 s per 10^5 reads through the front); MSQ_PACK_WIDE_STAGING=1 keeps the records.  Records a callback writes
+    // (the BAM front) go into the pinned buffer as they are: decoding them is what that path waits for, a second pass
+    // over them wins nothing (measured)
+    const char* wide = getenv("MSQ_PACK_WIDE_STAGING");
+    const bool compact = bake_thr != nullptr && !fill && !(wide && wide[0] == '1');
+    const size_t stage_bytes = std::max<size_t>(compact ? cap : cap * 8, 64);  // pinned: allocating it is most of a first call
     const unsigned n_thr = threads > 0 ? std::min(64u, (unsigned)threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
 
     // staging: two pinned host buffers (kept by the context), one device buffer + the error words in the scratch
@@ -485,12 +491,6 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
         if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "base offsets", e);
     }
 
-    // the baked packer over the caller's own records stages one translated byte per base (compact_records: 0.040 instead
-    // of 0.056 s per 10^5 reads through the front); MSQ_PACK_WIDE_STAGING=1 keeps the records.  Records a callback writes
-    // (the BAM front) go into the pinned buffer as they are: decoding them is what that path waits for, a second pass
-    // over them wins nothing (measured)
-    const char* wide = getenv("MSQ_PACK_WIDE_STAGING");
-    const bool compact = bake_thr != nullptr && !fill && !(wide && wide[0] == '1');
     unsigned long long host_bad = ~0ull;  // first unknown cigar seen while compacting: (base index << 8) | char
     uint64_t r0 = 0;
     for (int chunk = 0; r0 < n_reads; ++chunk) {
