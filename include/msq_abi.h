@@ -188,6 +188,28 @@ int msq_pack_reads_device_fill_baked(msq_ctx* ctx, uint64_t n_reads, const int32
                                      const int64_t* n_bases, msq_fill_read_fn fill, void* user, uint32_t pack_flags,
                                      int threads, int64_t chunk_bases, const msq_qv_thresholds* thr, msq_packed_dev** out);
 
+/* The thresholded packer for a producer that can TRANSLATE while it decodes (no counterpart in the reference: the walk
+ * of MSAByRow::AddRead, src/MSA.cpp:158-184, and ArrayBase::MeetQVThresholds, ArrayRead.inl:67-87, done by the callee
+ * base by base): the callback writes ONE byte per base instead of an 8-byte record,
+ *     byte = msq_compact_table()[(uint8_t)Cigar | (uint8_t)Nucleotide << 8]
+ *          = nucleotide code | op << 2 | (exotic symbol) << 4 | (inserted base that is not ACGT) << 5, 0x80 = unknown cigar,
+ * with msq_compact_fail() applied to the byte of a base that misses one of the run's thresholds (the caller knows them:
+ * it passes them on in thr only so that the set can be flagged).  presence: OR 1 into it when some base carries a
+ * QualQV, 2 when some base carries the rich QVs (that decides MSQ_READS_QV_BAKED as in the other packers).
+ * Returns -1, or for the first base with an unknown cigar its index in the read << 8 | the cigar char
+ * (the packer then fails with MSQ_ERR_CIGAR "Unexpected cigar <code>" for the first one in read order, src/MSA.cpp:182).
+ * Same packed bytes as msq_pack_reads_device_fill_baked on the records the bytes stand for. */
+typedef int64_t (*msq_fill_read_compact_fn)(void* user, uint64_t read_index, uint8_t* dst, uint32_t* presence);
+int msq_pack_reads_device_fill_compact(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                       const int64_t* n_bases, msq_fill_read_compact_fn fill, void* user, uint32_t pack_flags,
+                                       int threads, int64_t chunk_bases, const msq_qv_thresholds* thr, msq_packed_dev** out);
+const uint8_t* msq_compact_table(void); /* [65536], valid for the life of the process */
+/* a '=' / 'X' base (op 0, or one of the exotic match symbols under op 1) that misses a threshold reads 'N' (MSA.cpp:163-166) */
+uint8_t msq_compact_fail(uint8_t c); /* (c & 0x30) | 5 for those bases, c for every other */
+/* the same rule for a decoder's inner loop (no call per base): op = c >> 2 & 3, code = c & 3 */
+#define MSQ_COMPACT_FAIL(c) \
+    ((uint8_t)((((c) & 0x0cu) == 0u || (((c) & 0x0cu) == 0x04u && ((c) & 2u))) ? (((c) & 0x30u) | 5u) : (c)))
+
 /* ----------------------------------------------------------------------------------------------- pileup
  * MSAByRow::UpdateBoundaries over all reads (src/MSA.cpp:96-97,138-142): begin0 = min ReferenceStart,
  * end0 = max ReferenceEnd (0-based; MSAByRow::BeginPos()/EndPos() report begin0+1 / end0+1, MSA.cpp:107-108).

@@ -106,6 +106,9 @@ _SIGNATURES = {
     "msq_pack_reads_device_fill": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(_P)]),
     "msq_pack_reads_device_baked": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(QvThresholds), C.POINTER(_P)]),
     "msq_pack_reads_device_fill_baked": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(QvThresholds), C.POINTER(_P)]),
+    "msq_pack_reads_device_fill_compact": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(QvThresholds), C.POINTER(_P)]),
+    "msq_compact_table": (C.POINTER(C.c_uint8), []),
+    "msq_compact_fail": (C.c_uint8, [C.c_uint8]),
     "msq_insertion_counts": (C.c_int, [_P, C.POINTER(PackedReads), C.c_int32, C.c_int32, _P]),
     "msq_insertion_records": (C.c_int, [_P, C.POINTER(PackedReads), C.c_int32, C.c_int32, _P, _P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "msq_window_bounds": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -416,6 +416,10 @@ struct BamUtils
             DecodeBases(&loaded->data[k.off], k.block_size, k.ref_start, k.ref_end, regionStart, regionEnd, filePath,
                         [&dst](const Data::ArrayBase& b) { *dst++ = b; });
         };
+        source.fillCompact = [loaded, regionStart, regionEnd, filePath](uint64_t read, uint8_t* dst, const msq_qv_thresholds& thr, uint32_t* presence) {
+            const Kept& k = loaded->kept[read];
+            return DecodeBasesCompact(&loaded->data[k.off], k.block_size, k.ref_start, k.ref_end, regionStart, regionEnd, filePath, thr, dst, presence);
+        };
         if (timings) {
             timings->read = loaded->t_read;
             timings->inflate = loaded->t_inflate;
@@ -630,6 +634,39 @@ private:
             }
         }
         return n;
+    }
+
+    /// The same walk with every base translated on the spot (Data::ReadSource::fillCompact): one byte per base through
+    /// the library's table over (Cigar, Nucleotide), msq_compact_fail where a QV misses a threshold
+    /// (ArrayBase::MeetQVThresholds, ArrayRead.inl:67-87: every base DecodeBases makes carries a QualQV, and the rich
+    /// QVs when the record has all three tags).  Returns -1 or (index << 8 | cigar) of the first base whose cigar the
+    /// reference's MSA would throw on.
+    static int64_t DecodeBasesCompact(const uint8_t* rec, size_t block_size, int64_t ref_start, int64_t ref_end, int regionStart, int regionEnd,
+                                      const std::string& filePath, const msq_qv_thresholds& thr, uint8_t* dst, uint32_t* presence)
+    {
+        static const uint8_t* const table = msq_compact_table();
+        const bool anyThr = thr.qual >= 0 || thr.del >= 0 || thr.sub >= 0 || thr.ins >= 0;
+        int64_t firstBad = -1, n = 0;
+        bool rich = false;
+        DecodeBases(rec, block_size, ref_start, ref_end, regionStart, regionEnd, filePath, [&](const Data::ArrayBase& b) {
+            uint8_t c = table[(uint8_t)b.Cigar | ((unsigned)(uint8_t)b.Nucleotide << 8)];
+            if (c & 0x80) {
+                if (firstBad < 0) firstBad = (n << 8) | (uint8_t)b.Cigar;
+                c = 12;
+            } else if (anyThr) {
+                // without branches: on real QVs the outcome is as good as random per base (an unset threshold is -1:
+                // no QV is below it)
+                const unsigned fail = ((unsigned)b.HasQualQV & (unsigned)((int)b.QualQV < thr.qual)) |
+                                      ((unsigned)b.HasRichQVs & ((unsigned)((int)b.DelQV < thr.del) | (unsigned)((int)b.SubQV < thr.sub) |
+                                                                 (unsigned)((int)b.InsQV < thr.ins)));
+                const uint8_t masked = MSQ_COMPACT_FAIL(c);
+                c = fail ? masked : c;
+            }
+            rich = rich || b.HasRichQVs;
+            dst[n++] = c;
+        });
+        if (n) *presence |= 1u | (rich ? 2u : 0u);
+        return firstBad;
     }
 
     /// BAMArrayRead's constructor (src/ArrayRead.cpp:53-99) on the record clipped to the region: one ArrayBase per

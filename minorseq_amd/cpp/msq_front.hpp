@@ -226,6 +226,11 @@ struct ReadSource
     std::vector<int32_t> referenceStart, referenceEnd;
     std::vector<int64_t> numBases;
     std::function<void(uint64_t read, ArrayBase* dst)> fill;
+    /// Optional: the same read as one translated byte per base (msq_pack_reads_device_fill_compact in msq_abi.h: the
+    /// table over (Cigar, Nucleotide), msq_compact_fail on a base that misses a threshold); returns -1 or
+    /// (index of the first base with an unknown cigar) << 8 | that cigar.  A producer that decodes and translates in
+    /// one go (the BAM front) saves the 8-byte records; used when present.
+    std::function<int64_t(uint64_t read, uint8_t* dst, const msq_qv_thresholds& thr, uint32_t* presence)> fillCompact;
 };
 
 class MSAByRow  // include/pacbio/data/MSA.h:59-93
@@ -254,15 +259,32 @@ public:
                     if (!self->error) self->error = std::current_exception();
                 }
             }
-        } relay{&source, shareFirst_, {}, nullptr};
+            static int64_t FillCompact(void* user, uint64_t read, uint8_t* dst, uint32_t* presence)
+            {
+                Relay* self = static_cast<Relay*>(user);
+                try {
+                    return self->source->fillCompact(self->first + read, dst, self->thr, presence);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lock(self->mutex);
+                    if (!self->error) self->error = std::current_exception();
+                }
+                return -1;
+            }
+            msq_qv_thresholds thr;
+        } relay{&source, shareFirst_, {}, nullptr, {qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV}};
         msq_packed_dev* dev = nullptr;
         const uint32_t packFlags = insertions == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
         // the thresholds are fixed for the life of the MSA (MSA.h:82): they are applied while packing -- failing match
         // bases become the 'N' AddRead writes (src/MSA.cpp:165-166) and no QV plane ever reaches HBM
-        const msq_qv_thresholds thr{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
-        const int rc = msq_pack_reads_device_fill_baked(Msq::Context(), shareCount_, source.referenceStart.data() + shareFirst_,
-                                                        source.referenceEnd.data() + shareFirst_, source.numBases.data() + shareFirst_,
-                                                        &Relay::Fill, &relay, packFlags, 0, 0, &thr, &dev);
+        const msq_qv_thresholds thr = relay.thr;
+        const char* wide = std::getenv("MSQ_PACK_WIDE_STAGING");  // 1: the 8-byte records even from a producer that can translate
+        const bool compact = source.fillCompact && !(wide && wide[0] == '1');
+        const int rc = compact ? msq_pack_reads_device_fill_compact(Msq::Context(), shareCount_, source.referenceStart.data() + shareFirst_,
+                                                                    source.referenceEnd.data() + shareFirst_, source.numBases.data() + shareFirst_,
+                                                                    &Relay::FillCompact, &relay, packFlags, 0, 0, &thr, &dev)
+                               : msq_pack_reads_device_fill_baked(Msq::Context(), shareCount_, source.referenceStart.data() + shareFirst_,
+                                                                  source.referenceEnd.data() + shareFirst_, source.numBases.data() + shareFirst_,
+                                                                  &Relay::Fill, &relay, packFlags, 0, 0, &thr, &dev);
         if (relay.error) {
             if (dev) msq_packed_dev_free(Msq::Context(), dev);
             std::rethrow_exception(relay.error);

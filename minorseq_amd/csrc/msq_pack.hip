@@ -303,6 +303,12 @@ static uint64_t copy_or(uint64_t* dst, const msq_array_base* src, int64_t n)
 // everything the kernel would derive from a record is derived here, where the record is read anyway -- translation
 // (encode_base, through a table over (Cigar, Nucleotide)), the threshold test (ArrayRead.inl:67-87) and its 'N' -- and
 // an eighth of the bytes crosses PCIe: byte = code | op << 2 | exotic << 4 | inserted-exotic << 5; 0x80 = unknown cigar.
+extern "C" uint8_t msq_compact_fail(uint8_t c)
+{
+    const unsigned op = (c >> 2) & 3u, code = c & 3u;
+    return (op == 0 || (op == 1 && code >= 2)) ? (uint8_t)((c & 0x30u) | 5u) : c;  // op 1, code 1
+}
+
 struct CompactTable {
     uint8_t t[65536];
     CompactTable()
@@ -339,10 +345,11 @@ static uint64_t compact_records(uint8_t* dst, const void* src, int64_t n, const 
         } else if (any_thr) {
             const bool hq = (w >> 16) & 0xff, hr = (w >> 24) & 0xff;
             const int qq = (int)((w >> 32) & 0xff), qd = (int)((w >> 40) & 0xff), qs = (int)((w >> 48) & 0xff), qi = (int)((w >> 56) & 0xff);
-            const bool pass = (thr.qual < 0 || !hq || qq >= thr.qual) && (thr.del < 0 || !hr || qd >= thr.del) &&
-                              (thr.sub < 0 || !hr || qs >= thr.sub) && (thr.ins < 0 || !hr || qi >= thr.ins);
-            const unsigned op = (c >> 2) & 3u, code = c & 3u;
-            if (!pass && (op == 0 || (op == 1 && code >= 2))) c = (uint8_t)((c & 0x30) | 5);  // op 1, code 1: the literal 'N' (MSA.cpp:163-166)
+            // without branches (on real QVs the outcome is as good as random per base); an unset threshold is -1: no QV is below it
+            const unsigned fail = ((unsigned)hq & (unsigned)(qq < thr.qual)) |
+                                  ((unsigned)hr & ((unsigned)(qd < thr.del) | (unsigned)(qs < thr.sub) | (unsigned)(qi < thr.ins)));
+            const uint8_t masked = MSQ_COMPACT_FAIL(c);  // op 1, code 1: the literal 'N' (MSA.cpp:163-166)
+            c = fail ? masked : c;
         }
         dst[i] = c;
     }
@@ -398,12 +405,12 @@ static uint64_t stage_read_compact(uint8_t* dst, uint64_t r, uint64_t base0, con
 static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
                                   const msq_array_base* const* bases, const int64_t* n_bases, msq_fill_read_fn fill,
                                   void* user, uint32_t pack_flags, int threads, int64_t chunk_bases, const msq_qv_thresholds* bake_thr,
-                                  msq_packed_dev** out)
+                                  msq_packed_dev** out, msq_fill_read_compact_fn cfill = nullptr)
 {
     static_assert(sizeof(msq_array_base) == 8, "msq_array_base is one 8-byte record");
     if (!ctx || !out) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL argument");
     *out = nullptr;
-    if (n_reads && (!ref_start || !ref_end || (!bases && !fill) || !n_bases)) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL array");
+    if (n_reads && (!ref_start || !ref_end || (!bases && !fill && !cfill) || !n_bases)) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: NULL array");
     if (pack_flags & ~MSQ_PACK_PLAIN) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: unknown pack flag");
     const int plain = (pack_flags & MSQ_PACK_PLAIN) ? 1 : 0;
     msq_qv_thresholds thr{-1, -1, -1, -1};
@@ -426,7 +433,7 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
     }
     base_off[0] = group_off[0] = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
-        if (n_bases[r] < 0 || (n_bases[r] > 0 && !fill && !bases[r])) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: bad read %llu", (unsigned long long)r);
+        if (n_bases[r] < 0 || (n_bases[r] > 0 && !fill && !cfill && !bases[r])) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device: bad read %llu", (unsigned long long)r);
         base_off[r + 1] = base_off[r] + (uint64_t)n_bases[r];
         group_off[r + 1] = group_off[r] + (uint64_t)(n_bases[r] + 31) / 32;
         longest = std::max(longest, n_bases[r]);
@@ -439,7 +446,7 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
     // (the BAM front) go into the pinned buffer as they are: decoding them is what that path waits for, a second pass
     // over them wins nothing (measured)
     const char* wide = getenv("MSQ_PACK_WIDE_STAGING");
-    const bool compact = bake_thr != nullptr && !fill && !(wide && wide[0] == '1');
+    const bool compact = cfill != nullptr || (bake_thr != nullptr && !fill && !(wide && wide[0] == '1'));  // cfill: the caller's bytes
     const size_t stage_bytes = std::max<size_t>(compact ? cap : cap * 8, 64);  // pinned: allocating it is most of a first call
     const unsigned n_thr = threads > 0 ? std::min(64u, (unsigned)threads) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
 
@@ -509,6 +516,15 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
         // one read into this chunk's staging, in the mode of the call
         auto stage_one = [&](uint64_t r, std::vector<uint64_t>& tmp, unsigned long long* bad) -> uint64_t {
             const uint64_t at = base_off[r] - base_off[r0];
+            if (cfill) {  // the callee translated: its bytes, what it saw of the QVs, its first unknown cigar
+                uint32_t presence = 0;
+                const int64_t first_bad = cfill(user, r, hs8 + at, &presence);
+                if (first_bad >= 0) {
+                    const unsigned long long key = ((unsigned long long)(base_off[r] + (uint64_t)(first_bad >> 8)) << 8) | (unsigned long long)(first_bad & 0xff);
+                    if (key < *bad) *bad = key;
+                }
+                return ((presence & 1u) ? 1ull << 16 : 0ull) | ((presence & 2u) ? 1ull << 24 : 0ull);
+            }
             return compact ? stage_read_compact(hs8 + at, r, base_off[r], bases, n_bases, fill, user, tmp, thr, bad)
                            : stage_read(hs + at, r, bases, n_bases, fill, user);
         };
@@ -664,6 +680,17 @@ extern "C" int msq_pack_reads_device_fill(msq_ctx* ctx, uint64_t n_reads, const 
 {
     if (!fill) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device_fill: fill is NULL");
     return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, nullptr, n_bases, fill, user, pack_flags, threads, chunk_bases, nullptr, out);
+}
+
+extern "C" const uint8_t* msq_compact_table(void) { return compact_table().t; }
+
+extern "C" int msq_pack_reads_device_fill_compact(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
+                                                  const int64_t* n_bases, msq_fill_read_compact_fn fill, void* user, uint32_t pack_flags,
+                                                  int threads, int64_t chunk_bases, const msq_qv_thresholds* thr, msq_packed_dev** out)
+{
+    if (!fill) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device_fill_compact: fill is NULL");
+    if (!thr) return msq_fail(MSQ_ERR_ARG, "msq_pack_reads_device_fill_compact: thr is NULL");
+    return pack_reads_device_impl(ctx, n_reads, ref_start, ref_end, nullptr, n_bases, nullptr, user, pack_flags, threads, chunk_bases, thr, out, fill);
 }
 
 extern "C" int msq_pack_reads_device_fill_baked(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,

@@ -310,12 +310,19 @@ def test_bam_to_counts_matches_oracle(tmp_path, ref, rich):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("staging", ["compact", "records"])
 @pytest.mark.parametrize("rich,clean,region", [(False, True, (31, 391)), (True, True, (0, INT_MAX)), (True, False, (100, 300))])
-def test_direct_decode_equals_array_read_path(tmp_path, ref, rich, clean, region):
+def test_direct_decode_equals_array_read_path(tmp_path, monkeypatch, ref, rich, clean, region, staging):
     """BamToReadSource + AminoAcidCaller(ReadSource) -- records decoded straight into the device packer's staging
     buffer -- against BamToArrayReads + AminoAcidCaller(reads): the same names, intervals and base counts, and an
     identical dump (counts, codons, variants, p-values), also for records with soft clips, pads, N ops, absent
     QUAL and mixed rich tags (`clean=False`: those only through the read tables, the caller refuses 'N' cigars)."""
+    # staging: the decoder translates base by base into one byte each (fillCompact, the default), or writes the 8-byte
+    # records; with thresholds in the environment that mask bases (the front reads them per MSA, QvThresholds.cpp:45-56)
+    monkeypatch.setenv("MSQ_PACK_WIDE_STAGING", "0" if staging == "compact" else "1")
+    if rich:
+        monkeypatch.setenv("QUALQV", "30")
+        monkeypatch.setenv("DELQV", "40")
     rng = np.random.default_rng(31 + rich + 2 * clean)
     recs = make_records(rng, ref, 1200, clean=clean, rich=rich)
     path = str(tmp_path / "d.bam")
