@@ -92,11 +92,26 @@ __global__ __launch_bounds__(256) void segment_flags_kernel(const uint16_t* __re
         const uint16_t* a = keys + (uint64_t)idx[i] * K;
         const uint16_t* b = keys + (uint64_t)idx[i - 1] * K;
         f = 0;
-        for (int k = 0; k < K; ++k)
-            if (a[k] != b[k]) {
-                f = 1;
-                break;
-            }
+        const uintptr_t base = reinterpret_cast<uintptr_t>(keys);
+        if ((K & 3) == 0 && (base & 7) == 0) {  // rows of a multiple of four keys start on 8-byte boundaries: four keys per compare
+            const uint64_t* a8 = reinterpret_cast<const uint64_t*>(a);
+            const uint64_t* b8 = reinterpret_cast<const uint64_t*>(b);
+            uint64_t diff = 0;
+            for (int k = 0; k < (K >> 2); ++k) diff |= a8[k] ^ b8[k];
+            f = diff != 0;
+        } else if ((K & 1) == 0 && (base & 3) == 0) {
+            const uint32_t* a4 = reinterpret_cast<const uint32_t*>(a);
+            const uint32_t* b4 = reinterpret_cast<const uint32_t*>(b);
+            uint32_t diff = 0;
+            for (int k = 0; k < (K >> 1); ++k) diff |= a4[k] ^ b4[k];
+            f = diff != 0;
+        } else {
+            for (int k = 0; k < K; ++k)
+                if (a[k] != b[k]) {
+                    f = 1;
+                    break;
+                }
+        }
         if (f) atomicOr(collision, 1u);
     }
     flag[i] = f;

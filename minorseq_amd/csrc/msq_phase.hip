@@ -160,7 +160,9 @@ extern "C" int msq_phase_codons(msq_ctx* ctx, const msq_packed_reads* d_reads, c
         const double groups_per_read = (double)d_reads->n_groups / (double)d_reads->n_reads;
         const int n_slabs = ((W + 31) / 32 + 127) / 128;
         const char* force = getenv("MSQ_PHASE_LOOKUP");  // 1: always (when applicable), 0: never
-        const bool pays = force ? force[0] == '1' : 8.4 * (double)n_pos < groups_per_read * (3.8 * n_slabs - 2.0);
+        // taken when it is at least 15 % ahead of a streaming pass priced without its per-position share (which hides
+        // behind the decode for a few dozen positions): pol reads up to 10 positions, the 9.7 kb genome up to ~200
+        const bool pays = force ? force[0] == '1' : 11.0 * (double)n_pos < groups_per_read * (0.85 * 3.8 * n_slabs - 2.0);
         if (d_reads->gcol && !qv && !(d_reads->flags & MSQ_READS_HAS_EXOTIC) && d_reads->n_groups && pays && win_begin0 >= 0 &&
             (int64_t)win_begin0 + W < 0x1fffff00 && (uint64_t)d_reads->n_reads * (uint64_t)n_pos < (1ull << 38)) {
             void* s = nullptr;

@@ -130,7 +130,7 @@ def test_a_read_that_leaves_the_window(ctx, monkeypatch):
     monkeypatch.delenv("MSQ_PHASE_LOOKUP")
 
 
-@pytest.mark.parametrize("name,n,K,lookup", [("hiv_mix_200k", 30000, 20, True), ("amp20k_10m", 8000, 50, True), ("pol_100k", 30000, 40, False), ("pol_100k", 30000, 5, True),
+@pytest.mark.parametrize("name,n,K,lookup", [("hiv_mix_200k", 30000, 20, True), ("amp20k_10m", 8000, 50, True), ("pol_100k", 30000, 20, False), ("pol_100k", 30000, 5, True),
                                              ("hiv_mix_200k", 4000, 400, False)])
 def test_workloads_and_the_default_choice(ctx, monkeypatch, name, n, K, lookup):
     wl = synth.workload(name, n_reads=n)
