@@ -644,28 +644,100 @@ private:
     static int64_t DecodeBasesCompact(const uint8_t* rec, size_t block_size, int64_t ref_start, int64_t ref_end, int regionStart, int regionEnd,
                                       const std::string& filePath, const msq_qv_thresholds& thr, uint8_t* dst, uint32_t* presence)
     {
-        static const uint8_t* const table = msq_compact_table();
-        const bool anyThr = thr.qual >= 0 || thr.del >= 0 || thr.sub >= 0 || thr.ins >= 0;
-        int64_t firstBad = -1, n = 0;
-        bool rich = false;
-        DecodeBases(rec, block_size, ref_start, ref_end, regionStart, regionEnd, filePath, [&](const Data::ArrayBase& b) {
-            uint8_t c = table[(uint8_t)b.Cigar | ((unsigned)(uint8_t)b.Nucleotide << 8)];
-            if (c & 0x80) {
-                if (firstBad < 0) firstBad = (n << 8) | (uint8_t)b.Cigar;
-                c = 12;
-            } else if (anyThr) {
-                // without branches: on real QVs the outcome is as good as random per base (an unset threshold is -1:
-                // no QV is below it)
-                const unsigned fail = ((unsigned)b.HasQualQV & (unsigned)((int)b.QualQV < thr.qual)) |
-                                      ((unsigned)b.HasRichQVs & ((unsigned)((int)b.DelQV < thr.del) | (unsigned)((int)b.SubQV < thr.sub) |
-                                                                 (unsigned)((int)b.InsQV < thr.ins)));
-                const uint8_t masked = MSQ_COMPACT_FAIL(c);
-                c = fail ? masked : c;
+        using namespace detail;
+        // per cigar op the byte of each of the sixteen SEQ codes ("=ACMGRSVTWYHKDBN"), and of the op's placeholder
+        // base ('-' for D / N, '*' for P): the library's table, looked up once per process
+        struct Rows {
+            uint8_t seq[9][16], gap[9];
+            Rows()
+            {
+                static const char kSeq[] = "=ACMGRSVTWYHKDBN";
+                static const char kOps[] = "MIDNSHP=X";
+                const uint8_t* table = msq_compact_table();
+                for (int op = 0; op < 9; ++op) {
+                    for (int v = 0; v < 16; ++v) seq[op][v] = table[(uint8_t)kOps[op] | ((unsigned)(uint8_t)kSeq[v] << 8)];
+                    gap[op] = table[(uint8_t)kOps[op] | ((unsigned)(uint8_t)(op == 6 ? '*' : '-') << 8)];
+                }
             }
-            rich = rich || b.HasRichQVs;
-            dst[n++] = c;
-        });
-        if (n) *presence |= 1u | (rich ? 2u : 0u);
+        };
+        static const Rows rows;
+        static const char kOps[] = "MIDNSHP=X";
+        const size_t l_read_name = rec[8];
+        const size_t n_cigar = U16(rec + 12);
+        const uint16_t flag = U16(rec + 14);
+        const size_t l_seq = U32(rec + 16);
+        const uint8_t* cigar = rec + 32 + l_read_name;
+        const uint8_t* seq = cigar + 4 * n_cigar;
+        const uint8_t* qual = seq + (l_seq + 1) / 2;
+        const uint8_t* tags = qual + l_seq;
+        const uint8_t* end = rec + block_size;
+        const bool hasQual = l_seq > 0 && qual[0] != 0xFF;
+        const uint8_t *sq = nullptr, *dq = nullptr, *iq = nullptr;
+        size_t nsq = 0, ndq = 0, niq = 0;
+        const bool rich = FindZTag(tags, end, 's', 'q', &sq, &nsq) && FindZTag(tags, end, 'd', 'q', &dq, &ndq) &&
+                          FindZTag(tags, end, 'i', 'q', &iq, &niq) && nsq == l_seq && ndq == l_seq && niq == l_seq;
+        const bool reverse = flag & 0x10;
+        const bool anyThr = thr.qual >= 0 || thr.del >= 0 || thr.sub >= 0 || thr.ins >= 0;
+        const int64_t clip_lo = std::max<int64_t>(ref_start, regionStart), clip_hi = std::min<int64_t>(ref_end, regionEnd);
+        int64_t rp = ref_start, firstBad = -1;
+        size_t qp = 0;
+        uint8_t* out = dst;
+        for (size_t k = 0; k < n_cigar; ++k) {
+            const uint32_t cg = U32(cigar + 4 * k);
+            const int op = cg & 15;
+            const size_t len = cg >> 4;
+            if (op > 8) throw std::runtime_error("bad CIGAR op in " + filePath);
+            const bool cons_ref = op == 0 || op == 2 || op == 3 || op == 7 || op == 8;
+            const bool cons_query = op == 0 || op == 1 || op == 4 || op == 7 || op == 8;
+            if (cons_query && qp + len > l_seq) throw std::runtime_error("CIGAR longer than SEQ in " + filePath);
+            if (op == 4 || op == 5) {  // clips are excised
+                if (cons_query) qp += len;
+                continue;
+            }
+            size_t skip = 0, count = len;  // the part of the run inside the clip interval, as in DecodeBases
+            if (cons_ref) {
+                const int64_t first = std::max<int64_t>(rp, clip_lo), last = std::min<int64_t>(rp + (int64_t)len, clip_hi);
+                skip = (size_t)std::max<int64_t>(first - rp, 0);
+                count = last > first ? (size_t)(last - first) : 0;
+            } else if (!(rp >= clip_lo && rp <= clip_hi)) {
+                count = 0;
+            }
+            if (count && ((cons_query ? rows.seq[op][1] : rows.gap[op]) & 0x80)) {  // a cigar the MSA throws on ('M', 'N')
+                if (firstBad < 0) firstBad = ((int64_t)(out - dst) << 8) | (uint8_t)kOps[op];
+                std::memset(out, 12, count);
+                out += count;
+            } else if (cons_query) {
+                const uint8_t* row = rows.seq[op];
+                const size_t q0 = qp + skip, q1 = q0 + count;
+                if (!anyThr) {
+                    for (size_t q = q0; q < q1; ++q) *out++ = row[(seq[q >> 1] >> ((q & 1) ? 0 : 4)) & 15];
+                } else {
+                    // ArrayBase::MeetQVThresholds (ArrayRead.inl:67-87) without branches; every base of a record carries a
+                    // QualQV (0 without QUAL, ArrayRead.cpp:94-96), the rich QVs when all three tags are there
+                    for (size_t q = q0; q < q1; ++q) {
+                        const uint8_t c = row[(seq[q >> 1] >> ((q & 1) ? 0 : 4)) & 15];
+                        unsigned fail = (unsigned)((int)(hasQual ? qual[q] : 0) < thr.qual);
+                        if (rich) {
+                            const size_t i = reverse ? l_seq - 1 - q : q;  // tags are native-oriented; SEQ / QUAL genomic
+                            fail |= (unsigned)((int)(uint8_t)(dq[i] - 33) < thr.del) | (unsigned)((int)(uint8_t)(sq[i] - 33) < thr.sub) |
+                                    (unsigned)((int)(uint8_t)(iq[i] - 33) < thr.ins);
+                        }
+                        const uint8_t masked = MSQ_COMPACT_FAIL(c);
+                        *out++ = fail ? masked : c;
+                    }
+                }
+            } else if (count) {
+                // a placeholder base ('-' / '*', QualQV 0): a threshold can only turn a match symbol into 'N', and the
+                // table makes none of these one
+                uint8_t c = rows.gap[op];
+                if (anyThr && (0 < thr.qual || (rich && (0 < thr.del || 0 < thr.sub || 0 < thr.ins)))) c = MSQ_COMPACT_FAIL(c);
+                std::memset(out, c, count);
+                out += count;
+            }
+            if (cons_query) qp += len;
+            if (cons_ref) rp += (int64_t)len;
+        }
+        if (out != dst) *presence |= 1u | (rich ? 2u : 0u);
         return firstBad;
     }
 
