@@ -86,11 +86,25 @@ def parse():
     ap.add_argument("--sub-rate", type=float, default=-1.0, help="substitution errors per base (default 0.0005244257)")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-worker", default="", help=argparse.SUPPRESS)  # name:first:n -> prints the oracle's seconds
-    ap.add_argument("--h2d-steps", type=int, default=0, help="also time K steps that first copy the packed reads from "
-                    "pinned host memory (PCIe-inclusive rate, reported beside `value`, never as it)")
+    ap.add_argument("--h2d-steps", type=int, default=-1, help="also time K steps that first copy the packed reads from "
+                    "pinned host memory (PCIe-inclusive rate, reported beside `value`, never as it); default: 3 on the "
+                    "default one-GPU line, 0 elsewhere")
+    ap.add_argument("--project-strong", type=int, default=-1, help="one GPU: also time the shard one of this many GPUs would "
+                    "hold in a strong-scaling run of the same sample (1/n of the reads, the step's collectives issued on a "
+                    "one-rank communicator) and report T(all) / (n T(shard)) as `strong_projection` -- a ceiling: no xGMI "
+                    "time is in it; default: 8 on the default one-GPU line, 0 (off) elsewhere")
+    ap.add_argument("--launch-dry-run", action="store_true", help="--gpus N > 1 started as a plain `python bench.py`: print "
+                    "the command and environment of every rank process the launcher would start, and stop")
     a = ap.parse_args()
     if a.host_bounds:
         a.window = "host"
+    # the default one-GPU line carries the PCIe-inclusive rate and the strong-scaling projection beside `value`
+    plain = (a.gpus == 1 and not a.force_dist and a.qualqv < 0 and not a.rich and a.mode == "auto" and a.window == "known"
+             and not a.unfused and a.reads == 0 and a.workload in ("pol_1m", "pol_100k"))
+    if a.h2d_steps < 0:
+        a.h2d_steps = 3 if plain else 0
+    if a.project_strong < 0:
+        a.project_strong = 8 if plain else 0
     return a
 
 
@@ -163,6 +177,88 @@ def cpu_baseline(name, sample):
             "sample": "first %d reads of the same synthetic workload, %.1f s on one host core (oracle/liborc.so)" % (sample, dt1),
             "all_cores": {"value": procs * per / max(dts), "unit": "reads/s", "cores": procs,
                           "sample": "%d processes x %d reads, slowest %.1f s" % (procs, per, max(dts))}}
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_commands(a, argv, port):
+    """The rank processes of `python bench.py --gpus N` (N > 1, no launcher around it): one fresh interpreter per GPU,
+    the environment torch.distributed.run would give it, rendezvous on loopback."""
+    argv = [x for x in argv if x != "--launch-dry-run"]
+    cmds = []
+    for r in range(a.gpus):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(a.gpus), "LOCAL_WORLD_SIZE": str(a.gpus),
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "GLOO_SOCKET_IFNAME": "lo",
+               "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               "MSQ_BENCH_LAUNCHED": "1"}  # the parent holds the CPU baseline: rank 0 does not time it again
+        cmds.append({"rank": r, "argv": [sys.executable, "-u", os.path.abspath(__file__)] + argv, "env": env})
+    return cmds
+
+
+def launch(a):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: this process never touches the GPU (no torch import,
+    no HIP library) -- it times the CPU baseline, starts N rank processes, relays rank 0's JSON line with
+    `cpu_baseline` merged in, and fails when any rank fails."""
+    import subprocess
+    cmds = rank_commands(a, sys.argv[1:], free_port())
+    if a.launch_dry_run:
+        print(json.dumps({"launcher": "bench.py", "ranks": cmds}))
+        return 0
+    cpu = None
+    if a.cpu_sample > 0:
+        from minorseq_amd import synth as _synth
+        cpu = cpu_baseline(a.workload, min(a.cpu_sample, a.reads or _synth.workload(a.workload).n_reads))
+    procs = []
+    for c in cmds:
+        env = dict(os.environ)
+        env.update(c["env"])
+        # rank 0's stdout carries the line; the other ranks print nothing there, and whatever they do print goes to stderr
+        procs.append(subprocess.Popen(c["argv"], env=env, stdout=subprocess.PIPE if c["rank"] == 0 else sys.stderr,
+                                      text=True if c["rank"] == 0 else None))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    live = set(range(len(procs)))
+    while live and rc == 0:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = code if code > 0 else 128 - code
+                print("bench: rank %d exited with %d" % (r, code), file=sys.stderr)
+                break
+        time.sleep(0.05)
+    if rc:  # one rank failed: the others would wait for it in a collective for ever -- end exactly the ones started here
+        for r in live:
+            procs[r].terminate()
+        t_end = time.time() + 10.0
+        for r in live:
+            try:
+                procs[r].wait(max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+        return rc
+    reader.join(10.0)
+    lines = [ln for ln in "".join(out0).splitlines() if ln.startswith("{")]
+    if not lines:
+        print("bench: rank 0 printed no JSON line", file=sys.stderr)
+        return 1
+    out = json.loads(lines[-1])
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    out.setdefault("config", {})["launcher"] = "bench.py started %d rank processes itself (no WORLD_SIZE in its environment)" % a.gpus
+    print(json.dumps(out))
+    return 0
 
 
 class Run:
@@ -331,10 +427,24 @@ def main():
         name, first, n = a.cpu_worker.split(":")
         print(_cpu_worker((name, int(first), int(n))))
         return
-    cpu = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.cpu_sample > 0:
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:  # a plain `python bench.py --gpus N`: start the ranks ourselves
+        sys.exit(launch(a))
+    if a.launch_dry_run:
+        raise SystemExit("--launch-dry-run describes the launcher of a plain `python bench.py --gpus N` with N > 1")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus %d` (it starts its own ranks) or "
+                         "under torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus, a.gpus))
+
+    def cpu_now():
         from minorseq_amd import synth as _synth
-        cpu = cpu_baseline(a.workload, min(a.cpu_sample, a.reads or _synth.workload(a.workload).n_reads))
+        return cpu_baseline(a.workload, min(a.cpu_sample, a.reads or _synth.workload(a.workload).n_reads))
+    # the CPU baseline is timed before this job touches the GPU: here at N = 1; by the launcher when bench.py started
+    # the ranks itself; by rank 0 behind the rendezvous (the other ranks wait in a barrier) under torch.distributed.run
+    want_cpu = a.cpu_sample > 0 and rank == 0 and os.environ.get("MSQ_BENCH_LAUNCHED") != "1"
+    cpu = cpu_now() if (want_cpu and world == 1) else None
     # stdout carries the ONE JSON line and nothing else: whatever libraries print while the run is set up (RCCL's
     # version banner, for one) goes to stderr
     sys.stdout.flush()
@@ -342,36 +452,45 @@ def main():
     os.dup2(2, 1)
     import torch
     import torch.distributed as dist
-    from minorseq_amd import device, sharding, synth
+    from minorseq_amd import abi, device, sharding, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (a.gpus, world, a.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local)
-    ctx = device.Ctx(local)
+    n_dev = torch.cuda.device_count()  # counting does not initialise the GPU
+    if n_dev <= local or n_dev < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit("bench.py --gpus %d needs %d GPUs, found %d" % (a.gpus, a.gpus, n_dev))
     multi = world > 1 or a.force_dist
-    if multi:
+    if world > 1:
         # control plane only (the communicator id, the barrier, the max-over-ranks clock): gloo over loopback; the
         # data path is the library's RCCL communicator on the context's stream
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        ex_note = None
-        try:
-            if a.exchange == "torch":
-                raise RuntimeError("--exchange torch")
-            ex, err = sharding.LibExchange(ctx, rank, world, sharding.torch_bootstrap), ""
-        except Exception as e:  # noqa: BLE001 -- reported in the JSON line
-            ex, err = None, "%s: %s" % (type(e).__name__, e)
-        # every rank must take the same road: one that could not make its communicator sends all of them to
-        # torch.distributed's RCCL (same collectives, same stream), and the line says so
+        if want_cpu:
+            cpu = cpu_now()
+        dist.barrier()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    ctx = device.Ctx(local)
+    ex_note = None
+    if world > 1:
+        # every rank must take the same road.  msq_comm_create is a collective (ncclCommInitRank): a rank that cannot
+        # even load RCCL must say so BEFORE the others enter it, so the ranks first agree on a local, non-collective
+        # check (msq_comm_available) and only then create the communicator; if any of them cannot, all of them take
+        # torch.distributed's RCCL group (same collectives, same stream), and the line says so
+        err = "--exchange torch" if a.exchange == "torch" else ""
+        if not err and abi.lib().msq_comm_available() != abi.MSQ_OK:
+            err = abi.lib().msq_last_error().decode("utf-8", "replace")
         bad = [None] * world
         dist.all_gather_object(bad, err)
+        ex = None
+        if not any(bad):
+            try:
+                ex = sharding.LibExchange(ctx, rank, world, sharding.torch_bootstrap)
+                err = ""
+            except Exception as e:  # noqa: BLE001 -- reported in the JSON line
+                ex, err = None, "%s: %s" % (type(e).__name__, e)
+            dist.all_gather_object(bad, err)
         if any(bad):
             if ex is not None:
                 ex.close()
@@ -381,22 +500,25 @@ def main():
                 def allreduce_bounds(self, begin0, end0):
                     return sharding.TorchExchange.allreduce_bounds(self, begin0, end0, device=torch.device("cuda", local))
             ex = _CudaTorchExchange(grp)
-            ex_note = "torch.distributed RCCL group (the library communicator failed: %s)" % next(b for b in bad if b)
+            ex_note = "torch.distributed RCCL group over %d ranks (the library communicator was not used: %s)" % (world, next(b for b in bad if b))
             print("bench: " + ex_note, file=sys.stderr)
+    elif a.force_dist:  # rehearsal on one GPU: a one-rank communicator, no process group needed
+        ex = sharding.LibExchange(ctx, 0, 1, lambda raw: raw)
     else:
-        ex, ex_note = sharding.NoExchange(), None
+        ex = sharding.NoExchange()
+    comm_ranks = abi.lib().msq_comm_world(ctx.h) if isinstance(ex, sharding.LibExchange) else None
 
     wl = synth.workload(a.workload, **workload_kwargs(a))
     reads = a.reads or wl.n_reads
 
     def barrier():
         torch.cuda.synchronize()
-        if multi:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if not multi:
+        if world == 1:
             return x
         t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -453,6 +575,30 @@ def main():
                 "host_bytes_per_step": int(sum(h.numel() * h.element_size() for h in host.values()))}
         del host
 
+    projection = None
+    if a.project_strong > 1 and world == 1:
+        # what a strong-scaling run over n GPUs can reach at best: one rank's shard (1/n of the sample's reads, inside the
+        # sample's window, the log-factorial table of the whole sample) with the step's collectives issued on a
+        # one-rank communicator -- RCCL's launch is in it, xGMI time is not
+        n = a.project_strong
+        ex1 = None
+        try:
+            ex1 = ex if isinstance(ex, sharding.LibExchange) else sharding.LibExchange(ctx, 0, 1, lambda raw: raw)
+            first1, n1 = sharding.shard_range(reads, 0, n)
+            run1 = Run(a, ctx, ex1, wl, first1, n1, reads, (run.b0, run.e0))
+            dt1s, k1_ms, p1_ms, _ = run1.timed(barrier)
+            t_all, t_shard = dt / a.steps, dt1s / a.steps
+            projection = {"ranks": n, "reads_per_gpu": n1, "ms_per_step": t_shard * 1e3, "kernel_ms": k1_ms, "path_ms": p1_ms,
+                          "efficiency_ceiling": t_all / (n * t_shard),
+                          "note": "derived, not measured on %d GPUs: T(%d reads) / (%d x T(%d reads)) on ONE GPU, the shard's step with "
+                                  "its RCCL group issued on a one-rank communicator; xGMI time is not in it" % (n, reads, n, n1)}
+            del run1
+        except Exception as e:  # noqa: BLE001 -- the line says why the projection is missing
+            projection = {"ranks": n, "error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            if ex1 is not None and ex1 is not ex:
+                ex1.close()
+
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         # N * (1.001 * W * 1.5 + 12) -- bit planes + one QV byte per base.  Rich reads are priced by the QV
@@ -470,6 +616,14 @@ def main():
         kernel_name = "pileup_simple_kernel" if a.mode == "simple" else "pileup_kernel"
         traffic = None if (a.rich or a.scaling == "strong" and world > 1) else load_traffic(kernel_name, wl.name, shard_reads, a.qualqv, baked)
         physical = (traffic or real_bytes) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        limiter = "valu/latency" if physical < 0.8 * 6300.0 else "hbm"
+        # a leaner format than 1.5 B/base may exceed frac 1 only by reading less -- state the format
+        qv_read = 0 if baked else planes
+        fmt = "0.5 B/base bit planes (2-bit nucleotide + 2-bit op, sliced per 32-base group)" + \
+              (" + 0.125 B/base group column index" if indexed else "") + " + 12 B/read; " + \
+              ("%d QV plane%s read in the pass (1 B/base each)" % (qv_read, "" if qv_read == 1 else "s") if qv_read else
+               "QV planes not read: " + ("thresholds applied at pack time" if baked else "QUALQV unset, no threshold can mask a base")) + \
+              "; algorithmic bytes price 1.5 B/base as SURVEY 8d states them"
         out = {
             "metric": "aligned CCS reads/sec (pileup+Fisher, node)",
             "value": total / (dt / a.steps),
@@ -489,8 +643,9 @@ def main():
                 "unset" if a.qualqv < 0 else a.qualqv) + (", rich QVs, SUBQV=42" if a.rich else ""), "mode": a.mode,
                 "window": {"known": "known at set-up; bounds recomputed per step (inside the pileup kernel, msq_pileup_step; --unfused: in a launch of their own) and checked",
                            "device": "discovered on the device per step", "host": "host round trip per step"}[flow],
-                "exchange": (ex_note or ("one RCCL group per step (bounds MAX + counts SUM), library communicator" if flow == "known"
-                                          else "two RCCL all-reduces per step, library communicator")) if multi else "none (one GPU)",
+                "exchange": (ex_note or (("one RCCL group per step (bounds MAX + counts SUM)" if flow == "known" else "two RCCL all-reduces per step")
+                                          + ", library communicator (msq_comm_*) of %d rank%s as RCCL reports it" % (comm_ranks, "" if comm_ranks == 1 else "s")))
+                            if multi else "none (one GPU)",
                 "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 127) // 128),
                 "pileup_launches_per_step": run.launches_per_step,
                 "read_layout": "column-slab partition (built at set-up)" if n_slabs else "one read set",
@@ -499,14 +654,19 @@ def main():
                                  if run.spinup_steps else "none"),
                 "bases_per_gpu": int(n_bases), "codon_positions": P, "number_of_tests": n_tests,
                 "bases_off_majority": dev_share},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound` says what limits the kernel ("hbm" from 80 % of what a device copy reaches on this part, 6.3 TB/s,
+            # i.e. 5.0 TB/s of real traffic; "valu/latency" below); achieved / peak / frac are priced against the HBM
+            # roof either way (`roof`), with SURVEY 8d's algorithmic bytes
+            "roofline": {"bound": limiter, "roof": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("profiles/traffic.json (committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this kernel, workload "
+                                            "and size; not measured in this run)" if traffic else None),
+                         "format": fmt,
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes, "timed_steps": timed_steps,
                          # the physical side of the same launch: bytes really moved (PMC traffic when a pass of this
                          # exact configuration is committed, else the bytes the kernel streams) over the same time
                          "streamed_bytes": real_bytes, "column_index": indexed, "physical_gbs": physical, "frac_physical": physical / HBM_PEAK_GBS,
-                         # "hbm" from 80 % of what a device copy reaches on this part (6.3 TB/s), i.e. 5.0 TB/s
-                         "limiter": "valu/latency" if physical < 0.8 * 6300.0 else "hbm",
+                         "limiter": limiter,
                          # K1 + fold [+ exchange] + K2, SURVEY 8d's t_kernel(K1 + K2)
                          "path_ms": path_ms, "frac_path": (alg_bytes / (path_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if path_ms else None},
         }
@@ -518,10 +678,12 @@ def main():
             out["cpu_baseline"] = cpu
         if pcie is not None:
             out["pcie_inclusive"] = pcie
+        if projection is not None:
+            out["strong_projection"] = projection
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if multi:
-        ex.close()
+    ex.close()
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -376,6 +376,7 @@ int msq_timing_read_path(msq_ctx* ctx, float* ms_out, int32_t capacity, int32_t*
  * A context without a communicator treats every msq_comm_allreduce_* as a no-op (one GPU: the shard is the sample).
  * RCCL (librccl.so.1) is loaded when the first msq_comm_* call needs it; the single-GPU path does not depend on it. */
 #define MSQ_COMM_ID_BYTES 128
+int msq_comm_available(void);  /* MSQ_OK when RCCL can be loaded here: local, NOT collective -- ranks agree on it before msq_comm_create */
 int msq_comm_unique_id(uint8_t* id_out /* [MSQ_COMM_ID_BYTES] */);   /* host */
 int msq_comm_create(msq_ctx* ctx, int rank, int world, const uint8_t* id);  /* collective over the ranks; synchronises */
 int msq_comm_destroy(msq_ctx* ctx);
@@ -384,6 +385,16 @@ int msq_comm_rank(const msq_ctx* ctx);   /* 0 without a communicator */
 int msq_comm_world(const msq_ctx* ctx);  /* 1 without a communicator */
 /* Contiguous read range of a rank, [rank * N / world, (rank + 1) * N / world).  Host. */
 int msq_comm_shard(uint64_t n_reads, int rank, int world, uint64_t* first, uint64_t* count);
+/* The same, balanced by base count (SURVEY.md 8e "balanced by base count via base_offset") for reads that do not all
+ * span the window: prefix[i] = bases (or 32-base groups: group_off) of the reads before read i, n_reads + 1 entries,
+ * host; rank r starts at the first read i with prefix[i] >= ceil(r * prefix[n] / world).  Host. */
+int msq_comm_shard_bases(const uint64_t* prefix, uint64_t n_reads, int rank, int world, uint64_t* first, uint64_t* count);
+/* Collective: every rank hands in its local return code (its text: local_text, or msq_last_error() when NULL) and gets back the code of
+ * the LOWEST rank that failed, with that rank's text in msq_last_error() -- what a one-process run over the same reads
+ * reports first (the "Unexpected cigar" / "Unexpected base" of src/MSA.cpp:85,182 raised in one rank's share) -- or
+ * MSQ_OK.  A rank must call it before it throws, or the others wait for it in the next collective.  Synchronises.
+ * Without a communicator: *agreed_rc = local_rc. */
+int msq_comm_agree_status(msq_ctx* ctx, int local_rc, const char* local_text, int* agreed_rc);
 /* d_bounds = {-begin0, end0} as msq_window_bounds_device left it: element-wise MAX over the ranks, in place. */
 int msq_comm_allreduce_bounds(msq_ctx* ctx, int32_t* d_bounds);
 /* u32 SUM over the ranks, in place: the [W][6] + [W][64] count matrices (global read count < 2^32). */
@@ -426,6 +437,24 @@ typedef struct msq_error_model {
 /* ErrorEstimates(chemistry) src/ErrorEstimates.cpp:44-49 / ErrorEstimates(sub, del) :61-67.  Host. */
 int msq_error_model_default(msq_error_model* out);
 int msq_error_model_from_rates(double substitution_rate, double deletion_rate, msq_error_model* out);
+
+/* MSARow::Bases (include/pacbio/data/MSA.h:96-101; MSAByRow::AddRead, src/MSA.cpp:144-186) of reads
+ * [first_read, first_read + n_rows): d_rows[k * W + c] = the character AddRead leaves at window column c of read
+ * first_read + k -- one of "ACGT-N", or ' ' where the read has no base -- with the thresholds applied as in msq_pileup.
+ * What MSAByRow::Rows() of the C++ front materialises on first use; the counts never need it.  Async; deferred errors
+ * (a base outside the window, "Unexpected base") via msq_pileup_check. */
+int msq_rows_decode(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
+                    int32_t W, uint64_t first_read, uint64_t n_rows, char* d_rows /* [n_rows][W] */);
+
+/* Diagnostics (no counterpart in the reference; tests ask which path a call took): pileup calls of this process that
+ * ran the slabs of a wide window as one merged launch; msq_phase_codons calls that took the lookup gather.  (An
+ * experiment build with -DMSQ_WGT also exports msq_debug_wgt, per-workgroup clocks for tools/wgt.py; the shipped
+ * library does not.) */
+int msq_debug_merged_launches(void);
+int msq_debug_phase_lookups(void);
+/* Device memory the context has allocated so far and still holds (scratch, msq_pileup_step's deviation matrix, the
+ * log-factorial table): a call that promises not to allocate (msq_pileup_noalloc) leaves it unchanged. */
+uint64_t msq_debug_ctx_device_bytes(const msq_ctx* ctx);
 
 /* Reserve the log-factorial table factln(n) = lgamma(n+1.0), n <= max_n (src/Fisher.cpp:115-125), built on
  * the host with the same libm lgamma the reference calls and kept in HBM by the context.  A table that is

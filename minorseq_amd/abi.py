@@ -122,12 +122,19 @@ _SIGNATURES = {
     "msq_pileup": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P, C.c_int]),
     "msq_pileup_noalloc": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P]),
     "msq_pileup_check": (C.c_int, [_P]),
+    "msq_rows_decode": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P]),
+    "msq_debug_merged_launches": (C.c_int, []),
+    "msq_debug_phase_lookups": (C.c_int, []),
+    "msq_debug_ctx_device_bytes": (C.c_uint64, [_P]),
     "msq_phase_codons": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "msq_pileup_begin": (C.c_int, [_P, C.POINTER(PackedReads), _P, _P, C.c_size_t]),
     "msq_reads_index": (C.c_int, [_P, C.POINTER(PackedReads), _P]),
     "msq_pileup_step": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P]),
     "msq_timing_enable_strided": (C.c_int, [_P, C.c_int32, C.c_int32]),
     "msq_timing_read_path": (C.c_int, [_P, _P, C.c_int32, C.POINTER(C.c_int32)]),
+    "msq_comm_available": (C.c_int, []),
+    "msq_comm_shard_bases": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "msq_comm_agree_status": (C.c_int, [_P, C.c_int, C.c_char_p, C.POINTER(C.c_int)]),
     "msq_comm_unique_id": (C.c_int, [_P]),
     "msq_comm_create": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "msq_comm_destroy": (C.c_int, [_P]),

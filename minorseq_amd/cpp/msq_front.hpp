@@ -13,8 +13,10 @@
 //   PacBio::Juliet::TargetGene/DRM/DMutation/ExpectedMinor/TargetConfig (data members only) TargetConfig.h:49-139
 //   PacBio::Juliet::VariantGene                include/pacbio/juliet/VariantGene.h:49-81 (msa context as plain structs)
 //   PacBio::Juliet::AminoAcidCaller            include/pacbio/juliet/AminoAcidCaller.h:90-154 (CallVariants + store policy)
-// Per-read rows (MSAByRow::Rows()/NameToRow) are not materialised: PhaseVariants, their one consumer, gets the
-// codons it asks for from the device (MSAByRow::PhaseKeys).  Also here: the JSON report
+//   PacBio::Data::MSARow                       include/pacbio/data/MSA.h:96-110  (Bases, Insertions, Read, CodonAt, CodingCodonAt)
+// Per-read rows (MSAByRow::Rows() / NameToRow) are decoded on first use from the packed reads still in HBM
+// (msq_rows_decode + the insertion scan); the path itself never needs them -- PhaseVariants gets the codons it asks
+// for from the device (MSAByRow::PhaseKeys).  Also here: the JSON report
 // (msq_json.hpp), the --msa / --mode-error writers, MSAColumn::Insertions() and PacBio::Fuse::Fuse
 // (include/pacbio/fuse/Fuse.h:50-72), TargetConfig(input) from a JSON string or file.  Not mirrored: the HTML
 // report, the reference's built-in HIV configuration tables.
@@ -209,6 +211,40 @@ protected:
 // ---------------------------------------------------------------------------------------------------- MSA
 class MSAByColumn;
 
+/// A particular row of a MSA (include/pacbio/data/MSA.h:96-110): what AddRead makes of one read.
+struct MSARow
+{
+    MSARow(const int size) : Bases(size, ' ') {}
+    /// Individual bases with '-' as deletion, 'N' for a base under a QV threshold, ' ' where the read has nothing.
+    std::vector<char> Bases;
+    /// Position to insertion string.
+    std::map<int, std::string> Insertions;
+    /// The underlying ArrayRead (set by the shared_ptr constructor of MSAByRow, as in src/MSA.cpp:99-105).
+    std::shared_ptr<Data::ArrayRead> Read;
+
+    /// The row's characters at window columns pos, pos + 1, pos + 2, as far as they exist -- and column 0 never
+    /// does: the reference's loop asks for `i > 0` (src/MSA.cpp:188-195), which parity keeps.
+    std::string CodonAt(const int pos) const
+    {
+        std::string codon;
+        const int length = static_cast<int>(Bases.size());
+        for (int i = std::max(pos, 1); i < std::min(pos + 3, length); ++i) codon += Bases[i];
+        return codon;
+    }
+    /// true and *codon set when the read covers the three columns without a gap and CodonAt is one of the 64
+    /// codons of the amino-acid table (src/MSA.cpp:197-219); at winPos 0 CodonAt has two characters and never is.
+    bool CodingCodonAt(const int winPos, std::string* codon) const
+    {
+        if (winPos < 0 || winPos + 2 >= static_cast<int>(Bases.size())) return false;
+        for (int i = winPos; i < winPos + 3; ++i)
+            if (Bases[i] == ' ' || Bases[i] == '-') return false;
+        const std::string proposed = CodonAt(winPos);
+        if (!Juliet::AminoAcidTable::Has(proposed)) return false;
+        *codon = proposed;
+        return true;
+    }
+};
+
 /// MSAByRow: the pileup.  The reads are packed (msq_pack_reads), uploaded, and one msq_pileup builds both count
 /// matrices on the GPU; CodonsAt() and MSAByColumn read them back.
 /// Which per-column insertion histograms (MSARow::Insertions -> MSAColumn::Insertions(), src/MSA.cpp:88-90,151-156)
@@ -237,79 +273,40 @@ class MSAByRow  // include/pacbio/data/MSA.h:59-93
 {
 public:
     MSAByRow() = default;
+    /// The source must stay alive while Rows() / NameToRow() may still be called for the first time (they decode
+    /// lazily); the counts, CodonsAt and MSAByColumn need nothing from it after construction.
     MSAByRow(const ReadSource& source, InsertionMode insertions = InsertionMode::None)
     {
         const QvThresholds qv;
+        thr_ = msq_qv_thresholds{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
         numReads_ = source.names.size();
         names_ = source.names;
-        TakeShare(insertions);
-        struct Relay  // the callback crosses a C boundary: keep the first exception and rethrow it afterwards
-        {
-            const ReadSource* source;
-            uint64_t first;  // this rank's first read
-            std::mutex mutex;
-            std::exception_ptr error;
-            static void Fill(void* user, uint64_t read, msq_array_base* dst)
-            {
-                Relay* self = static_cast<Relay*>(user);
-                try {
-                    self->source->fill(self->first + read, reinterpret_cast<ArrayBase*>(dst));
-                } catch (...) {
-                    std::lock_guard<std::mutex> lock(self->mutex);
-                    if (!self->error) self->error = std::current_exception();
-                }
-            }
-            static int64_t FillCompact(void* user, uint64_t read, uint8_t* dst, uint32_t* presence)
-            {
-                Relay* self = static_cast<Relay*>(user);
-                try {
-                    return self->source->fillCompact(self->first + read, dst, self->thr, presence);
-                } catch (...) {
-                    std::lock_guard<std::mutex> lock(self->mutex);
-                    if (!self->error) self->error = std::current_exception();
-                }
-                return -1;
-            }
-            msq_qv_thresholds thr;
-        } relay{&source, shareFirst_, {}, nullptr, {qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV}};
-        msq_packed_dev* dev = nullptr;
-        const uint32_t packFlags = insertions == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
-        // the thresholds are fixed for the life of the MSA (MSA.h:82): they are applied while packing -- failing match
-        // bases become the 'N' AddRead writes (src/MSA.cpp:165-166) and no QV plane ever reaches HBM
-        const msq_qv_thresholds thr = relay.thr;
-        const char* wide = std::getenv("MSQ_PACK_WIDE_STAGING");  // 1: the 8-byte records even from a producer that can translate
-        const bool compact = source.fillCompact && !(wide && wide[0] == '1');
-        const int rc = compact ? msq_pack_reads_device_fill_compact(Msq::Context(), shareCount_, source.referenceStart.data() + shareFirst_,
-                                                                    source.referenceEnd.data() + shareFirst_, source.numBases.data() + shareFirst_,
-                                                                    &Relay::FillCompact, &relay, packFlags, 0, 0, &thr, &dev)
-                               : msq_pack_reads_device_fill_baked(Msq::Context(), shareCount_, source.referenceStart.data() + shareFirst_,
-                                                                  source.referenceEnd.data() + shareFirst_, source.numBases.data() + shareFirst_,
-                                                                  &Relay::Fill, &relay, packFlags, 0, 0, &thr, &dev);
-        if (relay.error) {
-            if (dev) msq_packed_dev_free(Msq::Context(), dev);
-            std::rethrow_exception(relay.error);
-        }
-        Msq::Check(rc);
-        Finish(dev, numReads_ == 0, qv, insertions, [&source, this](uint64_t read, uint32_t first, uint32_t len) {
-            read += shareFirst_;
-            std::vector<ArrayBase> bases((size_t)source.numBases[read], ArrayBase('P', '*'));
-            source.fill(read, bases.data());
+        const ReadSource* src = &source;
+        TakeShare(insertions, [src](size_t k) { return (uint64_t)src->numBases[k]; });
+        pack_ = [src](uint32_t packFlags, size_t first, size_t count, const msq_qv_thresholds& thr, msq_packed_dev** dev,
+                      std::exception_ptr* thrown) { return PackSource(*src, packFlags, first, count, thr, dev, thrown); };
+        basesOf_ = [src](uint64_t read, uint32_t first, uint32_t len) {
+            std::vector<ArrayBase> bases((size_t)src->numBases[read], ArrayBase('P', '*'));
+            src->fill(read, bases.data());
             std::string s(len, 'A');
             for (uint32_t i = 0; i < len; ++i) s[i] = bases[first + i].Nucleotide;
             return s;
-        });
+        };
+        Finish(PackShare(insertions == InsertionMode::None ? 0u : MSQ_PACK_PLAIN), numReads_ == 0, insertions);
     }
     MSAByRow(const std::vector<std::shared_ptr<Data::ArrayRead>>& reads, InsertionMode insertions = InsertionMode::None)
     {
         std::vector<const ArrayRead*> p;
         for (const auto& r : reads) p.push_back(r.get());
-        Build(p, insertions);
+        kept_ = reads;  // row.Read = r (src/MSA.cpp:101): the rows share the reads
+        Build(std::move(p), insertions);
     }
+    /// The vector must stay alive while Rows() / NameToRow() may still be called for the first time (see above).
     MSAByRow(const std::vector<Data::ArrayRead>& reads, InsertionMode insertions = InsertionMode::None)
     {
         std::vector<const ArrayRead*> p;
         for (const auto& r : reads) p.push_back(&r);
-        Build(p, insertions);
+        Build(std::move(p), insertions);
     }
     /// Per window column the insertion strings and their row counts (empty vector with InsertionMode::None).
     const std::vector<std::map<std::string, int>>& Insertions() const { return insertions_; }
@@ -317,6 +314,21 @@ public:
     int BeginPos() const { return beginPos_; }
     int EndPos() const { return endPos_; }
     int Width() const { return width_; }
+    /// The individual rows of the MSA (MSA.h:72).  The counts never need them, so they are decoded on first use: the
+    /// characters by msq_rows_decode from the packed reads still resident in HBM, the insertion strings by the
+    /// insertion scan (msq_insertion_records) over a plain-layout set -- the resident one when this MSA collects
+    /// insertions, else one packed again from the reads for this purpose.
+    const std::vector<std::shared_ptr<MSARow>>& Rows() const
+    {
+        Materialise();
+        return rows_;
+    }
+    /// Easy way to access a row by its name (MSA.h:75; std::out_of_range for an unknown name, as .at() there).
+    std::shared_ptr<MSARow> NameToRow(const std::string& name) const
+    {
+        Materialise();
+        return nameToRow_.at(name);
+    }
     /// Codon histogram at window column i (src/MSA.cpp:126-136): only observed codons appear, in codon order.
     std::map<std::string, int> CodonsAt(const int i) const
     {
@@ -403,20 +415,49 @@ public:
         }
         return codon;
     }
+    /// The read ranges of the ranks of a sharded MSA: rank r holds reads [ShareBounds()[r], ShareBounds()[r + 1]).
+    const std::vector<uint64_t>& ShareBounds() const { return shareBounds_; }
 
 private:
-    // This rank's share of a sample of numReads_ reads.  The insertion histogram is per read, not additive
-    // per column: an MSA that collects it keeps every read on every rank.
-    void TakeShare(InsertionMode insertions)
+    using PackFn = std::function<int(uint32_t packFlags, size_t first, size_t count, const msq_qv_thresholds& thr, msq_packed_dev** dev,
+                                     std::exception_ptr* thrown)>;
+    static void FreeDev(msq_packed_dev* d)
+    {
+        if (d) msq_packed_dev_free(Msq::Context(), d);
+    }
+    // One status for all ranks of a sharded MSA (msq_comm_agree_status): a rank that alone sees an error must not throw
+    // before the others know, or they wait for it in the next collective; every rank gets the code and text of the
+    // lowest failing rank -- the error a one-process run reports first -- and throws the same exception.
+    int Agree(int rc, const char* text = nullptr) const
+    {
+        if (!sharded_) return rc;
+        int agreed = rc;
+        Msq::Check(msq_comm_agree_status(Msq::Context(), rc, text, &agreed));
+        return agreed;
+    }
+    // This rank's share of a sample of numReads_ reads: contiguous read ranges balanced by BASE count
+    // (msq_comm_shard_bases) -- reads of an amplicon all span the window and the ranges are the equal read counts
+    // of msq_comm_shard; staggered or short reads would leave equal read counts up to 2x out of balance.  The
+    // insertion histogram is per read, not additive per column: an MSA that collects it keeps every read on every rank.
+    template <typename SizeOf>
+    void TakeShare(InsertionMode insertions, SizeOf sizeOf)
     {
         shareFirst_ = 0;
         shareCount_ = numReads_;
         sharded_ = Msq::CommActive() && insertions == InsertionMode::None;
+        shareBounds_ = {0, (uint64_t)numReads_};
         if (sharded_) {
-            uint64_t first = 0, count = 0;
-            Msq::Check(msq_comm_shard(numReads_, Msq::CommRank(), Msq::CommWorld(), &first, &count));
-            shareFirst_ = (size_t)first;
-            shareCount_ = (size_t)count;
+            const int world = Msq::CommWorld();
+            std::vector<uint64_t> prefix(numReads_ + 1, 0);
+            for (size_t k = 0; k < numReads_; ++k) prefix[k + 1] = prefix[k] + sizeOf(k);
+            shareBounds_.assign((size_t)world + 1, (uint64_t)numReads_);
+            for (int r = 0; r < world; ++r) {
+                uint64_t first = 0, count = 0;
+                Msq::Check(msq_comm_shard_bases(prefix.data(), numReads_, r, world, &first, &count));
+                shareBounds_[(size_t)r] = first;
+            }
+            shareFirst_ = (size_t)shareBounds_[(size_t)Msq::CommRank()];
+            shareCount_ = (size_t)(shareBounds_[(size_t)Msq::CommRank() + 1] - shareBounds_[(size_t)Msq::CommRank()]);
         }
     }
     // keys of all numReads_ reads into dKeys [numReads_][K]: this rank gathers its own reads' keys; on a sharded sample
@@ -427,26 +468,55 @@ private:
         const size_t K = pos.size();
         const bool sharded = sharded_;
         const int world = sharded ? Msq::CommWorld() : 1;
-        const size_t most = sharded ? (numReads_ + world - 1) / world : numReads_;  // the largest share
+        size_t most = numReads_;  // the largest share
+        if (sharded) {
+            most = 0;
+            for (int r = 0; r < world; ++r) most = std::max(most, (size_t)(shareBounds_[(size_t)r + 1] - shareBounds_[(size_t)r]));
+        }
         Msq::DeviceBuffer<uint16_t> dMine(sharded ? most * K : 0), dAll(sharded ? most * K * world : 0);
         uint16_t* const mine = sharded ? dMine.get() : dKeys;
-        Msq::Check(msq_phase_codons(ctx, msq_packed_dev_view(dev_.get()), &thr_, beginPos_ - 1, width_, (int32_t)K, pos.data(), mine));
-        Msq::Check(msq_pileup_check(ctx));
+        int rc = msq_phase_codons(ctx, msq_packed_dev_view(dev_.get()), &thr_, beginPos_ - 1, width_, (int32_t)K, pos.data(), mine);
+        if (rc == MSQ_OK) rc = msq_pileup_check(ctx);
+        Msq::Check(Agree(rc));  // before the collective: every rank gathers, or every rank throws
         if (!sharded) return;
         Msq::Check(msq_comm_allgather(ctx, dMine.get(), dAll.get(), most * K * sizeof(uint16_t)));
         for (int r = 0; r < world; ++r) {
-            uint64_t first = 0, count = 0;
-            Msq::Check(msq_comm_shard(numReads_, r, world, &first, &count));
+            const uint64_t first = shareBounds_[(size_t)r], count = shareBounds_[(size_t)r + 1] - first;
             Msq::Check(msq_memcpy_d2d(ctx, dKeys + first * K, dAll.get() + (size_t)r * most * K, count * K * sizeof(uint16_t)));
         }
         Msq::Check(msq_ctx_sync(ctx));
     }
     // The insertion histogram: count the recorded insertions per column on the GPU, pick the columns
     // that matter, fetch their (column, string) records and add them up.
-    /// basesOf(read, first, len): the literal nucleotide chars of ArrayBases [first, first + len) of a read -- asked
-    /// for the few runs the packed 2-bit form cannot hold (longer than 64 bases, or with a non-ACGT base).
-    void CollectInsertions(msq_ctx* ctx, const msq_packed_reads* view, int32_t b0, InsertionMode mode,
-                           const std::function<std::string(uint64_t, uint32_t, uint32_t)>& basesOf)
+    // basesOf_(read, first, len): the literal nucleotide chars of ArrayBases [first, first + len) of a read -- asked
+    // for the few runs the packed 2-bit form cannot hold (longer than 64 bases, or with a non-ACGT base).
+    /// visit(record, string) for every insertion a read records at a column the filter keeps (all columns: NULL)
+    template <typename Visit>
+    void ForEachInsertion(msq_ctx* ctx, const msq_packed_reads* view, int32_t b0, const std::vector<uint32_t>* filter, uint64_t capacity,
+                          Visit visit, size_t setFirstRead = SIZE_MAX) const
+    {
+        if (capacity == 0) return;
+        Msq::DeviceBuffer<uint32_t> dFilter(filter ? filter->size() : 1);
+        if (filter) Msq::Check(msq_memcpy_h2d(ctx, dFilter.get(), filter->data(), filter->size() * sizeof(uint32_t)));
+        Msq::DeviceBuffer<msq_insertion> dRecords(capacity);
+        uint64_t n = 0;
+        Msq::Check(msq_insertion_records(ctx, view, b0, width_, filter ? dFilter.get() : nullptr, dRecords.get(), capacity, &n));
+        const std::vector<msq_insertion> records = dRecords.ToHost();
+        static const char nt[] = "ACGT";
+        std::string s;
+        for (uint64_t k = 0; k < n; ++k) {
+            const msq_insertion& r = records[k];
+            if (r.len > 64 || (view->flags & MSQ_READS_INS_EXOTIC)) {
+                // any length, literal chars (src/MSA.cpp:151-156,172-174); a record counts reads from the set's first read
+                s = basesOf_((setFirstRead == SIZE_MAX ? shareFirst_ : setFirstRead) + r.read, r.first_base, r.len);
+            } else {
+                s.assign(r.len, 'A');
+                for (uint32_t i = 0; i < r.len; ++i) s[i] = nt[((i < 32 ? r.seq_lo >> (2 * i) : r.seq_hi >> (2 * (i - 32)))) & 3];
+            }
+            visit(r, s);
+        }
+    }
+    void CollectInsertions(msq_ctx* ctx, const msq_packed_reads* view, int32_t b0, InsertionMode mode)
     {
         insertions_.assign((size_t)width_, {});
         if (width_ == 0) return;
@@ -465,33 +535,142 @@ private:
             filter[c >> 5] |= 1u << (c & 31);
             capacity += total[c];
         }
-        if (capacity == 0) return;
-        Msq::DeviceBuffer<uint32_t> dFilter(filter.size());
-        Msq::Check(msq_memcpy_h2d(ctx, dFilter.get(), filter.data(), filter.size() * sizeof(uint32_t)));
-        Msq::DeviceBuffer<msq_insertion> dRecords(capacity);
-        uint64_t n = 0;
-        Msq::Check(msq_insertion_records(ctx, view, b0, width_, dFilter.get(), dRecords.get(), capacity, &n));
-        const std::vector<msq_insertion> records = dRecords.ToHost();
-        static const char nt[] = "ACGT";
-        std::string s;
-        for (uint64_t k = 0; k < n; ++k) {
-            const msq_insertion& r = records[k];
-            if (r.len > 64 || (view->flags & MSQ_READS_INS_EXOTIC)) {
-                s = basesOf(r.read, r.first_base, r.len);  // any length, literal chars (src/MSA.cpp:151-156,172-174)
-            } else {
-                s.assign(r.len, 'A');
-                for (uint32_t i = 0; i < r.len; ++i) s[i] = nt[((i < 32 ? r.seq_lo >> (2 * i) : r.seq_hi >> (2 * (i - 32)))) & 3];
-            }
-            ++insertions_[(size_t)r.col][s];
-        }
+        ForEachInsertion(ctx, view, b0, &filter, capacity, [this](const msq_insertion& r, const std::string& s) { ++insertions_[(size_t)r.col][s]; });
     }
 
-    void Build(const std::vector<const ArrayRead*>& reads, InsertionMode insertionMode)
+    // Rows() / NameToRow(): see Rows()
+    void Materialise() const
+    {
+        if (materialised_) return;
+        msq_ctx* ctx = Msq::Context();
+        const size_t n = numReads_, W = (size_t)width_;
+        std::vector<std::shared_ptr<MSARow>> rows;
+        rows.reserve(n);
+        for (size_t r = 0; r < n; ++r) rows.push_back(std::make_shared<MSARow>(width_));
+        if (n != 0 && W != 0) {
+            const int32_t b0 = beginPos_ - 1;
+            // row.Insertions: the scan needs the genomic order of inserted and column-consuming bases inside a group --
+            // the plain layout, which an MSA that collects insertions holds already; otherwise ALL reads are packed once
+            // more for this purpose (on one rank's share of a sharded sample too: every rank then decodes every row
+            // locally, no collective)
+            std::shared_ptr<msq_packed_dev> plain = dev_;
+            const msq_packed_reads* view = msq_packed_dev_view(dev_.get());
+            if (sharded_ || !(view->flags & MSQ_READS_PAD_MARKED) || (view->flags & MSQ_READS_NORMALIZED)) {
+                msq_packed_dev* again = nullptr;
+                std::exception_ptr thrown;
+                const int rc = pack_(MSQ_PACK_PLAIN, 0, n, thr_, &again, &thrown);
+                plain.reset(again, &FreeDev);
+                if (thrown) std::rethrow_exception(thrown);
+                Msq::Check(rc);
+            }
+            const msq_packed_reads* pv = msq_packed_dev_view(plain.get());
+            const msq_packed_reads* rowsView = sharded_ ? pv : view;  // the resident set when it holds every read
+            const size_t per = std::max<size_t>(1, std::min(n, (size_t(64) << 20) / W));  // rows per 64 MB round trip
+            Msq::DeviceBuffer<char> dRows(per * W);
+            std::vector<char> h(per * W);
+            for (size_t first = 0; first < n; first += per) {
+                const size_t count = std::min(per, n - first);
+                Msq::Check(msq_rows_decode(ctx, rowsView, &thr_, b0, width_, first, count, dRows.get()));
+                Msq::Check(msq_memcpy_d2h(ctx, h.data(), dRows.get(), count * W));
+                for (size_t k = 0; k < count; ++k) rows[first + k]->Bases.assign(h.begin() + k * W, h.begin() + (k + 1) * W);
+            }
+            Msq::Check(msq_pileup_check(ctx));
+            Msq::DeviceBuffer<uint32_t> dTotal(W);
+            Msq::Check(msq_insertion_counts(ctx, pv, b0, width_, dTotal.get()));
+            uint64_t capacity = 0;
+            for (const uint32_t t : dTotal.ToHost()) capacity += t;
+            ForEachInsertion(ctx, pv, b0, nullptr, capacity, [&rows](const msq_insertion& r, const std::string& s) { rows[r.read]->Insertions[(int)r.col] = s; },
+                             /* the plain set starts at read */ sharded_ ? 0 : shareFirst_);
+        }
+        for (size_t r = 0; r < n; ++r) {
+            if (r < kept_.size()) rows[r]->Read = kept_[r];
+            nameToRow_[names_[r]] = rows[r];  // a later read of the same name takes the entry (src/MSA.cpp:103)
+        }
+        rows_ = std::move(rows);
+        materialised_ = true;
+    }
+
+    // packs reads [first, first + count) of a ReadSource; *thrown = the first exception a fill callback raised
+    static int PackSource(const ReadSource& source, uint32_t packFlags, size_t first, size_t count, const msq_qv_thresholds& thr,
+                          msq_packed_dev** dev, std::exception_ptr* thrown)
+    {
+        struct Relay  // the callback crosses a C boundary: keep the first exception and hand it back afterwards
+        {
+            const ReadSource* source;
+            uint64_t first;  // this rank's first read
+            msq_qv_thresholds thr;
+            std::mutex mutex;
+            std::exception_ptr error;
+            static void Fill(void* user, uint64_t read, msq_array_base* dst)
+            {
+                Relay* self = static_cast<Relay*>(user);
+                try {
+                    self->source->fill(self->first + read, reinterpret_cast<ArrayBase*>(dst));
+                } catch (...) {
+                    std::lock_guard<std::mutex> lock(self->mutex);
+                    if (!self->error) self->error = std::current_exception();
+                }
+            }
+            static int64_t FillCompact(void* user, uint64_t read, uint8_t* dst, uint32_t* presence)
+            {
+                Relay* self = static_cast<Relay*>(user);
+                try {
+                    return self->source->fillCompact(self->first + read, dst, self->thr, presence);
+                } catch (...) {
+                    std::lock_guard<std::mutex> lock(self->mutex);
+                    if (!self->error) self->error = std::current_exception();
+                }
+                return -1;
+            }
+        } relay{&source, first, thr, {}, nullptr};
+        // the thresholds are fixed for the life of the MSA (MSA.h:82): they are applied while packing -- failing match
+        // bases become the 'N' AddRead writes (src/MSA.cpp:165-166) and no QV plane ever reaches HBM
+        const char* wide = std::getenv("MSQ_PACK_WIDE_STAGING");  // 1: the 8-byte records even from a producer that can translate
+        const bool compact = source.fillCompact && !(wide && wide[0] == '1');
+        const int rc = compact ? msq_pack_reads_device_fill_compact(Msq::Context(), count, source.referenceStart.data() + first,
+                                                                    source.referenceEnd.data() + first, source.numBases.data() + first,
+                                                                    &Relay::FillCompact, &relay, packFlags, 0, 0, &thr, dev)
+                               : msq_pack_reads_device_fill_baked(Msq::Context(), count, source.referenceStart.data() + first,
+                                                                  source.referenceEnd.data() + first, source.numBases.data() + first,
+                                                                  &Relay::Fill, &relay, packFlags, 0, 0, &thr, dev);
+        *thrown = relay.error;
+        return rc;
+    }
+    // this rank's share packed into HBM; on a sharded MSA the ranks agree on the outcome before any of them throws
+    msq_packed_dev* PackShare(uint32_t packFlags)
+    {
+        msq_packed_dev* dev = nullptr;
+        std::exception_ptr thrown;
+        int rc = pack_(packFlags, shareFirst_, shareCount_, thr_, &dev, &thrown);
+        std::string text;
+        if (thrown) {
+            rc = MSQ_ERR_ARG;
+            try {
+                std::rethrow_exception(thrown);
+            } catch (const std::exception& e) {
+                text = e.what();
+            } catch (...) {
+                text = "exception in a read source";
+            }
+        }
+        const int agreed = Agree(rc, thrown ? text.c_str() : nullptr);
+        if ((agreed != MSQ_OK || thrown) && dev) {
+            FreeDev(dev);
+            dev = nullptr;
+        }
+        if (thrown && !sharded_) std::rethrow_exception(thrown);  // one process: the producer's own exception
+        Msq::Check(agreed);  // "Unexpected cigar ..." -> std::runtime_error, the same on every rank
+        return dev;
+    }
+
+    void Build(std::vector<const ArrayRead*> readPointers, InsertionMode insertionMode)
     {
         const QvThresholds qv;  // member qvThresholds_ of the reference: read from the environment per MSA (MSA.h:82)
-        numReads_ = reads.size();
-        for (const auto* r : reads) names_.push_back(r->Name());
-        TakeShare(insertionMode);
+        thr_ = msq_qv_thresholds{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
+        const auto reads = std::make_shared<const std::vector<const ArrayRead*>>(std::move(readPointers));
+        numReads_ = reads->size();
+        for (const auto* r : *reads) names_.push_back(r->Name());
+        TakeShare(insertionMode, [&reads](size_t k) { return (uint64_t)(*reads)[k]->Bases().size(); });
         // the reads' ArrayBase arrays go to the GPU as they are (8-byte records); msq_pack_reads_device copies them
         // through pinned staging and translates / packs them on the device
         static_assert(sizeof(ArrayBase) == sizeof(msq_array_base) && offsetof(ArrayBase, Cigar) == offsetof(msq_array_base, cigar) &&
@@ -501,42 +680,39 @@ private:
                           offsetof(ArrayBase, QualQV) == offsetof(msq_array_base, qual) && offsetof(ArrayBase, DelQV) == offsetof(msq_array_base, del) &&
                           offsetof(ArrayBase, SubQV) == offsetof(msq_array_base, sub) && offsetof(ArrayBase, InsQV) == offsetof(msq_array_base, ins),
                       "ArrayBase is the ABI's msq_array_base");
-        std::vector<int32_t> rs, re;
-        std::vector<const msq_array_base*> ptr;
-        std::vector<int64_t> len;
-        rs.reserve(shareCount_);
-        re.reserve(shareCount_);
-        ptr.reserve(shareCount_);
-        len.reserve(shareCount_);
-        for (size_t k = shareFirst_; k < shareFirst_ + shareCount_; ++k) {
-            const ArrayRead* r = reads[k];
-            rs.push_back(r->ReferenceStart());
-            re.push_back(r->ReferenceEnd());
-            ptr.push_back(reinterpret_cast<const msq_array_base*>(r->Bases().data()));
-            len.push_back(static_cast<int64_t>(r->Bases().size()));
-        }
-        msq_ctx* ctx = Msq::Context();
-        msq_packed_dev* dev = nullptr;
-        // "Unexpected cigar ..." -> std::runtime_error
-        // the insertion scan needs the genomic order inside each group (plain layout); the pileup takes both
-        const uint32_t packFlags = insertionMode == InsertionMode::None ? 0u : MSQ_PACK_PLAIN;
-        const msq_qv_thresholds thr{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};  // applied while packing, as above
-        Msq::Check(msq_pack_reads_device_baked(ctx, shareCount_, rs.data(), re.data(), ptr.data(), len.data(), packFlags, 0, 0, &thr, &dev));
-        Finish(dev, reads.empty(), qv, insertionMode, [&reads, this](uint64_t read, uint32_t first, uint32_t len) {
+        pack_ = [reads](uint32_t packFlags, size_t first, size_t count, const msq_qv_thresholds& thr, msq_packed_dev** dev, std::exception_ptr*) {
+            std::vector<int32_t> rs, re;
+            std::vector<const msq_array_base*> ptr;
+            std::vector<int64_t> len;
+            rs.reserve(count);
+            re.reserve(count);
+            ptr.reserve(count);
+            len.reserve(count);
+            for (size_t k = first; k < first + count; ++k) {
+                const ArrayRead* r = (*reads)[k];
+                rs.push_back(r->ReferenceStart());
+                re.push_back(r->ReferenceEnd());
+                ptr.push_back(reinterpret_cast<const msq_array_base*>(r->Bases().data()));
+                len.push_back(static_cast<int64_t>(r->Bases().size()));
+            }
+            // the thresholds are applied while packing, as above
+            return msq_pack_reads_device_baked(Msq::Context(), count, rs.data(), re.data(), ptr.data(), len.data(), packFlags, 0, 0, &thr, dev);
+        };
+        basesOf_ = [reads](uint64_t read, uint32_t first, uint32_t len) {
             std::string s(len, 'A');
-            for (uint32_t i = 0; i < len; ++i) s[i] = reads[shareFirst_ + read]->Bases()[first + i].Nucleotide;
+            for (uint32_t i = 0; i < len; ++i) s[i] = (*reads)[read]->Bases()[first + i].Nucleotide;
             return s;
-        });
+        };
+        // the insertion scan needs the genomic order inside each group (plain layout); the pileup takes both
+        Finish(PackShare(insertionMode == InsertionMode::None ? 0u : MSQ_PACK_PLAIN), reads->empty(), insertionMode);
     }
 
     // window bounds, pileup and (on request) the insertion histogram of the packed reads now resident in HBM
-    void Finish(msq_packed_dev* dev, bool noReads, const QvThresholds& qv, InsertionMode insertionMode,
-                const std::function<std::string(uint64_t, uint32_t, uint32_t)>& basesOf)
+    void Finish(msq_packed_dev* dev, bool noReads, InsertionMode insertionMode)
     {
         struct EmptyTag { bool empty() const { return value; } bool value; } reads{noReads};
         msq_ctx* ctx = Msq::Context();
-        dev_.reset(dev, [](msq_packed_dev* d) { msq_packed_dev_free(Msq::Context(), d); });  // kept for PhaseKeys
-        thr_ = msq_qv_thresholds{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
+        dev_.reset(dev, &FreeDev);  // kept for PhaseKeys and Rows()
         {
             // UpdateBoundaries over this rank's reads, left in HBM as {-begin, end}; one MAX over the ranks makes it the
             // sample's window (a no-op without a communicator); then it comes to the host, which sizes the matrices
@@ -552,13 +728,14 @@ private:
             dCounts_.reset(new Msq::DeviceBuffer<uint32_t>((size_t)width_ * 70));
             uint32_t* const dNuc = dCounts_->get();
             uint32_t* const dCodon = dNuc + (size_t)width_ * 6;
-            Msq::Check(msq_pileup(ctx, msq_packed_dev_view(dev), &thr_, b0, width_, dNuc, dCodon, MSQ_PILEUP_AUTO));
+            int rc = msq_pileup(ctx, msq_packed_dev_view(dev), &thr_, b0, width_, dNuc, dCodon, MSQ_PILEUP_AUTO);
+            if (rc == MSQ_OK) rc = msq_pileup_check(ctx);  // "Unexpected base ..." -> std::runtime_error
+            Msq::Check(Agree(rc));                        // ... on every rank, before the collective
             if (sharded_) Msq::Check(msq_comm_allreduce_counts(ctx, dNuc, (size_t)width_ * 70));
-            Msq::Check(msq_pileup_check(ctx));  // "Unexpected base ..." -> std::runtime_error
             const std::vector<uint32_t> counts = dCounts_->ToHost();
             nuc_.assign(counts.begin(), counts.begin() + (size_t)width_ * 6);
             codon_.assign(counts.begin() + (size_t)width_ * 6, counts.end());
-            if (insertionMode != InsertionMode::None) CollectInsertions(ctx, msq_packed_dev_view(dev), b0, insertionMode, basesOf);
+            if (insertionMode != InsertionMode::None) CollectInsertions(ctx, msq_packed_dev_view(dev), b0, insertionMode);
         }
         if (!reads.empty()) {  // ++beginPos_, ++endPos_ (src/MSA.cpp:107-108)
             ++beginPos_;
@@ -576,14 +753,33 @@ private:
     std::vector<uint32_t> nuc_, codon_;
     std::shared_ptr<Msq::DeviceBuffer<uint32_t>> dCounts_;
     size_t shareFirst_ = 0, shareCount_ = 0;  // the reads this rank packed and piled up (all of them on one GPU)
+    std::vector<uint64_t> shareBounds_{0, 0};  // [world + 1] first read of every rank's share
     bool sharded_ = false;                    // a communicator is bound and this MSA took its share
     std::shared_ptr<msq_packed_dev> dev_;  // the packed reads stay in HBM for the phasing pass
     msq_qv_thresholds thr_{-1, -1, -1, -1};
     std::vector<std::string> names_;
     std::vector<std::map<std::string, int>> insertions_;
+    // for Rows(): how to pack the reads again, their literal bases, the reads the rows share, and the rows themselves
+    PackFn pack_;
+    std::function<std::string(uint64_t read, uint32_t first, uint32_t len)> basesOf_;
+    std::vector<std::shared_ptr<Data::ArrayRead>> kept_;
+    mutable std::vector<std::shared_ptr<MSARow>> rows_;
+    mutable std::map<std::string, std::shared_ptr<MSARow>> nameToRow_;
+    mutable bool materialised_ = false;
 };
 
-/// A single MSA column: counts per nucleotide {A, C, G, T, -, N}.
+/// Per-column results of a nucleotide-level Fisher test (include/pacbio/data/FisherResult.h:42-48; the reference
+/// declares it and juliet never fills one: "NOT YET USED", MSA.h:184-188).
+struct FisherResult
+{
+    std::array<double, 6> PValues = {{0, 0, 0, 0, 0, 0}};
+    std::array<double, 6> Mask = {{0, 0, 0, 0, 0, 0}};
+    bool Hit = false;
+    int ArgMax = 0;
+};
+
+/// A single MSA column: counts per nucleotide {A, C, G, T, -, N}, insertions, and the Fisher results a caller
+/// may attach.
 class MSAColumn  // include/pacbio/data/MSA.h:155-214
 {
 public:
@@ -614,10 +810,49 @@ public:
     /// Insertions and respective counts (MSA.h:179-180, MSA.inl:101-103); filled when the MSAByRow collected them.
     const std::map<std::string, int>& Insertions() const { return insertions_; }
     void IncInsertion(const std::string& seq) { insertions_[seq]++; }
+    /// P-value for given nucleotide: 1 until a FisherResult is attached (MSA.h:197, MSA.inl:105).
+    double PValue(const char c) const { return pValues_.at(Tag(c)); }
+    /// Insertions whose attached p-value is below 0.01, in string order (src/MSA.cpp:223-229).
+    std::vector<std::string> SignificantInsertions() const
+    {
+        std::vector<std::string> hits;
+        for (const auto& entry : insertionsPValues_)
+            if (entry.second < 0.01) hits.push_back(entry.first);
+        return hits;
+    }
+    void AddFisherResult(const FisherResult& f)  // src/MSA.cpp:231-237
+    {
+        pValues_ = f.PValues;
+        mask_ = f.Mask;
+        hit_ = f.Hit;
+        argMax_ = f.ArgMax;
+    }
+    void AddFisherResult(const std::map<std::string, double>& f) { insertionsPValues_ = f; }  // MSA.inl:82-85
+    /// "refPos<TAB>(-,count,p)<TAB>(ins,count,p)<TAB>...": the masked deletion and the significant insertions (MSA.inl:87-97)
+    std::ostream& InDels(std::ostream& stream)
+    {
+        stream << refPos_ << "\t";
+        if (mask_.at(4) == 1) stream << "(-," << counts_.at(4) << "," << pValues_.at(4) << ")\t";
+        for (const std::string& ins : SignificantInsertions())
+            stream << "(" << ins << "," << insertions_.at(ins) << "," << insertionsPValues_.at(ins) << ")\t";
+        stream << std::endl;
+        return stream;
+    }
+    /// the five counts A C G T -, each followed by a tab (MSA.inl:107-112)
+    friend std::ostream& operator<<(std::ostream& stream, const MSAColumn& r)
+    {
+        for (const char b : {'A', 'C', 'G', 'T', '-'}) stream << r[b] << "\t";
+        return stream;
+    }
 
 private:
     std::array<int, 6> counts_{{0, 0, 0, 0, 0, 0}};
     std::map<std::string, int> insertions_;
+    std::map<std::string, double> insertionsPValues_;
+    std::array<double, 6> pValues_{{1, 1, 1, 1, 1, 1}};
+    std::array<double, 6> mask_{{0, 0, 0, 0, 0, 0}};
+    bool hit_ = false;
+    int argMax_ = 0;
     int refPos_ = -1;
     friend class MSAByColumn;
 };
@@ -864,6 +1099,17 @@ struct PerformanceMetrics  // include/pacbio/juliet/AminoAcidCaller.h:55-78
         }
         text << '}';
         return text.str();
+    }
+    /// "TPR FPR tests accuracy FP" on one line (include/pacbio/juliet/internal/AminoAcidCaller.inl:42-47)
+    friend std::ostream& operator<<(std::ostream& out, const PerformanceMetrics& pm)
+    {
+        const double fields[] = {pm.TruePositiveRate(), pm.FalsePositiveRate(), pm.NumberOfTests, pm.Accuracy(), pm.FalsePositives};
+        const char* lead = "";
+        for (const double f : fields) {
+            out << lead << f;
+            lead = " ";
+        }
+        return out;
     }
 };
 
@@ -1302,6 +1548,13 @@ private:
                 }
             }
             variantGenes_.emplace_back(std::move(curVariantGene));
+        }
+        // with expected minors configured: the classification record goes to validation.json in the working directory
+        // and to stderr, as the reference writes them (src/AminoAcidCaller.cpp:571-576)
+        if (hasExpectedMinors) {
+            std::ofstream outValJson("validation.json");
+            outValJson << pm_->ToJson();
+            std::cerr << *pm_ << std::endl;
         }
     }
 

@@ -75,6 +75,10 @@ struct msq_comm {
 
 static_assert(MSQ_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "msq_comm_unique_id hands out an ncclUniqueId");
 
+// Can this process reach RCCL at all?  Local and non-collective: ranks agree on the answer over their control plane
+// BEFORE any of them enters msq_comm_create (ncclCommInitRank blocks until every rank has arrived).
+extern "C" int msq_comm_available(void) { return load_rccl(); }
+
 extern "C" int msq_comm_unique_id(uint8_t* id_out)
 {
     if (!id_out) return msq_fail(MSQ_ERR_ARG, "msq_comm_unique_id: id_out is NULL");
@@ -129,6 +133,79 @@ extern "C" int msq_comm_shard(uint64_t n_reads, int rank, int world, uint64_t* f
     const uint64_t lo = (uint64_t)(n * (unsigned)rank / (unsigned)world), hi = (uint64_t)(n * (unsigned)(rank + 1) / (unsigned)world);
     *first = lo;
     *count = hi - lo;
+    return MSQ_OK;
+}
+
+// Contiguous read range of a rank, balanced by BASE count ("balanced by base count via base_offset"):
+// with prefix[i] = units (bases or 32-base groups) of the reads before read i, rank r starts at the first read i with
+// prefix[i] >= r * prefix[n] / world.  Boundaries are monotone in r, so the ranges tile [0, n); reads of equal length
+// give msq_comm_shard's ranges up to one read.  Host; every rank computes every boundary from the same table.
+extern "C" int msq_comm_shard_bases(const uint64_t* prefix, uint64_t n_reads, int rank, int world, uint64_t* first, uint64_t* count)
+{
+    if (!first || !count || world < 1 || rank < 0 || rank >= world || (!prefix && n_reads))
+        return msq_fail(MSQ_ERR_ARG, "msq_comm_shard_bases: bad argument");
+    if (n_reads == 0) {
+        *first = *count = 0;
+        return MSQ_OK;
+    }
+    const unsigned __int128 total = prefix[n_reads];
+    auto boundary = [&](int r) -> uint64_t {
+        if (r <= 0) return 0;
+        if (r >= world) return n_reads;
+        const uint64_t want = (uint64_t)((total * (unsigned)r + (unsigned)world - 1) / (unsigned)world);  // ceil(r total / world)
+        uint64_t lo = 0, hi = n_reads;  // first i in [0, n] with prefix[i] >= want
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            if (prefix[mid] >= want) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    const uint64_t lo = boundary(rank), hi = boundary(rank + 1);
+    *first = lo;
+    *count = hi > lo ? hi - lo : 0;
+    return MSQ_OK;
+}
+
+// One rank's status -> every rank's status.  Collective.  An error that one rank alone detects ("Unexpected cigar" in
+// its share, a deferred "Unexpected base") must not make that rank leave while the others wait in the next
+// collective: every rank calls this with its local return code (and msq_last_error() text), and every rank gets back
+// the code and text of the LOWEST rank that failed -- the error a single-process run over the same reads would have
+// reported first -- or MSQ_OK.  local_text: the failing rank's message, NULL = msq_last_error() (an error raised above
+// the ABI, e.g. an exception in a fill callback, brings its own).  256 bytes per rank, all-gathered on the context's
+// stream; synchronises.
+extern "C" int msq_comm_agree_status(msq_ctx* ctx, int local_rc, const char* local_text, int* agreed_rc)
+{
+    if (!ctx || !agreed_rc) return msq_fail(MSQ_ERR_ARG, "msq_comm_agree_status: NULL argument");
+    *agreed_rc = local_rc;
+    if (!ctx->comm) {  // one process: its status is the status
+        if (local_rc != MSQ_OK && local_text) msq_set_error("%s", local_text);
+        return MSQ_OK;
+    }
+    MSQ_HIP(hipSetDevice(ctx->device));
+    struct Slot { int32_t rc; char text[252]; };
+    static_assert(sizeof(Slot) == 256, "one status slot");
+    const int world = ctx->comm->world;
+    std::vector<Slot> all((size_t)world);
+    Slot mine;
+    memset(&mine, 0, sizeof(mine));
+    mine.rc = local_rc;
+    if (local_rc != MSQ_OK) snprintf(mine.text, sizeof(mine.text), "%s", local_text ? local_text : msq_last_error());
+    void* d = nullptr;
+    if (int rc = msq_scratch(ctx, sizeof(Slot) * (size_t)(world + 1), &d)) return rc;
+    Slot* d_mine = static_cast<Slot*>(d);
+    Slot* d_all = d_mine + 1;
+    MSQ_HIP(hipMemcpyAsync(d_mine, &mine, sizeof(Slot), hipMemcpyHostToDevice, ctx->stream));
+    MSQ_RCCL(g_rccl.AllGather(d_mine, d_all, sizeof(Slot), ncclUint8, ctx->comm->comm, ctx->stream));
+    MSQ_HIP(hipMemcpyAsync(all.data(), d_all, sizeof(Slot) * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < world; ++r) {
+        if (all[(size_t)r].rc == MSQ_OK) continue;
+        all[(size_t)r].text[sizeof(all[(size_t)r].text) - 1] = 0;
+        *agreed_rc = all[(size_t)r].rc;
+        msq_set_error("%s", all[(size_t)r].text);
+        return MSQ_OK;
+    }
+    *agreed_rc = MSQ_OK;
     return MSQ_OK;
 }
 

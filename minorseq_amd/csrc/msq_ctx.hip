@@ -232,6 +232,15 @@ void msq_timing_mark_path_end(msq_ctx* ctx)  // behind msq_call_cells' last kern
     }
 }
 
+// Diagnostics: device memory the context has allocated so far and still holds (scratch, the step's deviation matrix,
+// the log-factorial table) -- a test of msq_pileup_noalloc asks that a call leaves it as it was.
+extern "C" uint64_t msq_debug_ctx_device_bytes(const msq_ctx* ctx)
+{
+    if (!ctx) return 0;
+    return (uint64_t)ctx->scratch_bytes + (uint64_t)ctx->dev_words * sizeof(uint32_t) +
+           (ctx->lfact_n >= 0 ? ((uint64_t)ctx->lfact_n + 1) * sizeof(double) : 0);
+}
+
 int msq_scratch(msq_ctx* ctx, size_t bytes, void** out)
 {
     if (bytes > ctx->scratch_bytes) {

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void index_groups_kernel(const int32_t* __rest
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t r = wave; r < n_reads; r += n_waves) {
         const uint64_t g_begin = group_off[r], g_end = group_off[r + 1];
-        uint32_t carry = (uint32_t)ref_start[r];
+        int64_t carry = ref_start[r];
         for (uint64_t blk = g_begin; blk < g_end; blk += 64) {
             const uint64_t g = blk + (uint64_t)lane;
             const int ncons = g < g_end ? __popc(~bop[g].w) : 0;
@@ -233,10 +233,14 @@ __global__ __launch_bounds__(256) void index_groups_kernel(const int32_t* __rest
                 if (lane >= d) incl += up;
             }
             // column + 1: a valid word is never 0 (what a load past the end of a batch returns)
-            // columns the 29 bits cannot hold saturate: such a group lies outside every window the kernels take an index
-            // for (stream_launch), and is reported there like any base outside the window
-            if (g < g_end) gcol[g] = min(carry + (uint32_t)(incl - ncons) + 1u, 0x1fffffffu) | ((uint32_t)(r & 7u) << 29);
-            carry += (uint32_t)__shfl(incl, 63);
+            // columns the 29 bits cannot hold -- beyond 2^29 - 2 or NEGATIVE (a read with ReferenceStart -1 must not
+            // yield the word 0, "lane past the batch") -- saturate: such a group lies outside every window the kernels
+            // take an index for (stream_launch: begin0 >= 0), and is reported there like any base outside the window
+            if (g < g_end) {
+                const int64_t c = carry + (incl - ncons);
+                gcol[g] = (c < 0 || c + 1 > 0x1fffffff ? 0x1fffffffu : (uint32_t)(c + 1)) | ((uint32_t)(r & 7u) << 29);
+            }
+            carry += __shfl(incl, 63);
         }
     }
 }

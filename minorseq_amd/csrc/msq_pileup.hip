@@ -213,6 +213,72 @@ static int launch_simple(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
     return MSQ_OK;
 }
 
+// ------------------------------------------------------------------------------------------ per-read rows
+// MSARow::Bases of reads [first, first + n) as the reference keeps them (MSARow(size): W chars, ' ' where the read
+// has nothing; AddRead, src/MSA.cpp:144-186): one wave per read builds the row in LDS exactly as the simple pileup
+// does and writes it out as characters (a wave stores 64 consecutive chars at a time; not a hot path).
+__global__ __launch_bounds__(256) void rows_decode_kernel(
+    const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ group_off, const uint4* __restrict__ bop,
+    QvPlanes qv, uint64_t first, uint64_t n, int32_t win_begin0, int32_t W, int32_t row_bytes, int32_t waves_per_wg,
+    char* __restrict__ rows, uint32_t* __restrict__ err)
+{
+    extern __shared__ __align__(16) uint8_t lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint8_t* row = lds + (size_t)wave * row_bytes;
+    const uint64_t total_waves = (uint64_t)gridDim.x * waves_per_wg;
+    const uint64_t iters = (n + total_waves - 1) / total_waves;
+    uint32_t my_err = 0;
+    for (uint64_t it = 0; it < iters; ++it) {
+        const uint64_t slot = it * total_waves + (uint64_t)blockIdx.x * waves_per_wg + wave;
+        const bool active = slot < n;
+        for (int c = lane * 4; c < row_bytes; c += 256) *reinterpret_cast<uint32_t*>(row + c) = 0;
+        __syncthreads();
+        if (active) my_err |= msq_build_row(row, lane, ref_start, group_off, bop, qv, first + slot, win_begin0, W);
+        __syncthreads();
+        if (active) {
+            char* out = rows + slot * (uint64_t)W;
+            for (int c = lane; c < W; c += 64) {
+                // SYM_* -> the chars of MSARow::Bases; a packed symbol has no other value
+                out[c] = (char)((0x004e2d5447434120ull >> (8 * row[c])) & 0xff);  // the bytes of " ACGT-N", ' ' lowest
+            }
+        }
+        __syncthreads();
+    }
+    if (my_err) atomicOr(err, my_err);
+}
+
+extern "C" int msq_rows_decode(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
+                               int32_t W, uint64_t first_read, uint64_t n_rows, char* d_rows)
+{
+    if (!ctx || !d_reads || !thr) return msq_fail(MSQ_ERR_ARG, "msq_rows_decode: NULL argument");
+    if (W < 0) return msq_fail(MSQ_ERR_ARG, "msq_rows_decode: negative window width %d", W);
+    if (first_read > d_reads->n_reads || n_rows > d_reads->n_reads - first_read)
+        return msq_fail(MSQ_ERR_ARG, "msq_rows_decode: rows [%llu, +%llu) of %llu reads", (unsigned long long)first_read,
+                        (unsigned long long)n_rows, (unsigned long long)d_reads->n_reads);
+    if (n_rows == 0 || W == 0) return MSQ_OK;
+    if (!d_rows) return msq_fail(MSQ_ERR_ARG, "msq_rows_decode: NULL row buffer");
+    if (int rc = msq_validate_reads(d_reads, thr, "msq_rows_decode")) return rc;
+    MSQ_HIP(hipSetDevice(ctx->device));
+    const int32_t row_bytes = ((W + 2 + 15) / 16) * 16;
+    int waves = 150 * 1024 / row_bytes;
+    if (waves < 1) return msq_fail(MSQ_ERR_ARG, "msq_rows_decode: window of %d columns exceeds one LDS row", W);
+    if (waves > 4) waves = 4;
+    const size_t lds = (size_t)row_bytes * waves;
+    if (lds > 48 * 1024)
+        MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rows_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint64_t blocks = (n_rows + waves - 1) / waves;
+    const uint64_t cap = (uint64_t)ctx->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    QvPlanes q;
+    q.plane[0] = d_reads->qual; q.plane[1] = d_reads->delqv; q.plane[2] = d_reads->subqv; q.plane[3] = d_reads->insqv;
+    q.thr[0] = thr->qual; q.thr[1] = thr->del; q.thr[2] = thr->sub; q.thr[3] = thr->ins;
+    hipLaunchKernelGGL(rows_decode_kernel, dim3((unsigned)blocks), dim3(64 * waves), lds, ctx->stream, d_reads->ref_start,
+                       d_reads->group_off, reinterpret_cast<const uint4*>(d_reads->bop), q, first_read, n_rows, win_begin0, W,
+                       row_bytes, waves, d_rows, ctx->d_err);
+    MSQ_HIP(hipGetLastError());
+    return MSQ_OK;
+}
+
 extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr,
                           int32_t win_begin0, int32_t W, uint32_t* d_nuc, uint32_t* d_codon, int mode)
 {

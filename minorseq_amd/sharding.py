@@ -26,6 +26,25 @@ def shard_range(n_reads, rank, world):
     return lo, hi - lo
 
 
+def shard_range_bases(prefix, rank, world):
+    """The same, balanced by base count (msq_comm_shard_bases): prefix[i] = bases (or groups) of the reads before read
+    i, n + 1 entries; rank r starts at the first read i with prefix[i] >= ceil(r * prefix[n] / world)."""
+    n = len(prefix) - 1
+    if n <= 0:
+        return 0, 0
+    total = int(prefix[n])
+
+    def boundary(r):
+        if r <= 0:
+            return 0
+        if r >= world:
+            return n
+        want = (total * r + world - 1) // world
+        return int(np.searchsorted(np.asarray(prefix), want, side="left"))
+    lo, hi = boundary(rank), boundary(rank + 1)
+    return lo, max(0, hi - lo)
+
+
 class LibExchange:
     """The library's RCCL communicator bound to a device.Ctx (msq_comm_create).  `bootstrap(id_bytes_or_None)` must
     return rank 0's 128-byte id on every rank (rank 0 passes its own in, the others None)."""

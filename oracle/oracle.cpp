@@ -349,6 +349,19 @@ int orc_col_insertions(void* h, int col, char* buf, int buflen)
     return (int)s.size();
 }
 
+// MSARow::Insertions of one row (MSA.h:102-103; filled by AddRead's CheckInsertion, MSA.cpp:151-156): writes
+// "POS:SEQ " tokens in map order.  Entries at pos == W (a flush behind the last column: an out-of-bounds write in
+// MSAByColumn, MSA.cpp:89) are kept here as the map holds them.
+int orc_row_insertions(void* h, int64_t row, char* buf, int buflen)
+{
+    Msa* m = static_cast<Msa*>(h);
+    std::string s;
+    for (const auto& kv : m->rows[(size_t)row].ins) s += std::to_string(kv.first) + ":" + kv.second + " ";
+    if ((int)s.size() + 1 > buflen) return -(int)s.size() - 1;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
 // Fuse::CreateConsensus with CollectInsertions and FindInsertions (src/tools/Fuse.cpp:70-140) on this MSA's
 // columns.  Keys are MSAColumn::RefPos() = the 1-based position (MSA.cpp:60-66).  Writes the consensus string.
 int orc_fuse(void* h, int min_coverage_recommended, char* buf, int buflen)

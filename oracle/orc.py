@@ -52,6 +52,8 @@ def lib():
         l.orc_col_maxbase.argtypes = [P, C.c_int]
         l.orc_col_insertions.restype = C.c_int
         l.orc_col_insertions.argtypes = [P, C.c_int, C.c_char_p, C.c_int]
+        l.orc_row_insertions.restype = C.c_int
+        l.orc_row_insertions.argtypes = [P, C.c_int64, C.c_char_p, C.c_int]
         l.orc_fuse.restype = C.c_int
         l.orc_fuse.argtypes = [P, C.c_int, C.c_char_p, C.c_int]
         l.orc_count_positions.restype = C.c_int64
@@ -202,6 +204,17 @@ class Msa:
             s, c = line.split("\t")
             out[s] = int(c)
         return out
+
+    def row_insertions(self, row):
+        """MSARow::Insertions of one row as {window column: string}."""
+        cap = 1 << 12
+        while True:
+            buf = C.create_string_buffer(cap)
+            n = lib().orc_row_insertions(self.h, int(row), buf, cap)
+            if n >= 0:
+                break
+            cap = -n + 16
+        return {int(t.split(":")[0]): t.split(":")[1] for t in buf.value.decode().split()}
 
     def fuse(self, min_coverage=50):
         """Fuse::CreateConsensus on this MSA (src/tools/Fuse.cpp:70-97)."""

@@ -110,6 +110,46 @@ static void DumpPhase(const char* name, Juliet::AminoAcidCaller& aac)
     std::printf("ENDPHASE\n");
 }
 
+// MSAByRow::Rows() / NameToRow() / MSARow (include/pacbio/data/MSA.h:72-75,96-110): every row's characters and
+// insertion map, and -- checked right here -- that the rows reproduce the MSA's own codon counts through
+// MSARow::CodingCodonAt exactly as MSAByRow::CodonsAt sums them up in the reference (src/MSA.cpp:126-136).
+static void DumpRows(const char* name, const Data::MSAByRow& msa, bool sharedReads)
+{
+    const auto& rows = msa.Rows();
+    std::printf("ROWS %s %zu %d\n", name, rows.size(), msa.Width());
+    for (size_t r = 0; r < rows.size(); ++r) {
+        std::string b(rows[r]->Bases.begin(), rows[r]->Bases.end());
+        for (auto& ch : b)
+            if (ch == ' ') ch = '_';
+        std::printf("ROW %zu %s", r, b.c_str());
+        for (const auto& kv : rows[r]->Insertions) std::printf(" %d:%s", kv.first, kv.second.c_str());
+        std::putchar('\n');
+    }
+    bool codonsEqual = true, byName = true, readsShared = true;
+    std::string codon;
+    for (int i = -1; i <= msa.Width(); ++i) {
+        std::map<std::string, int> fromRows;
+        for (const auto& row : rows)
+            if (row->CodingCodonAt(i, &codon)) ++fromRows[codon];
+        codonsEqual = codonsEqual && fromRows == msa.CodonsAt(i);
+    }
+    for (size_t r = 0; r < rows.size(); ++r) {
+        byName = byName && msa.NameToRow(msa.ReadNames()[r]) == rows[r];
+        readsShared = readsShared && (sharedReads ? (rows[r]->Read && rows[r]->Read->Name() == msa.ReadNames()[r]) : !rows[r]->Read);
+    }
+    bool unknownThrows = false;
+    try {
+        msa.NameToRow("no such read");
+    } catch (const std::out_of_range&) {
+        unknownThrows = true;
+    }
+    // CodonAt keeps the reference's `i > 0`: at 0 two characters, inside three, at the right edge what is left
+    const std::string first = rows.empty() ? "" : rows[0]->CodonAt(0), last = rows.empty() ? "" : rows[0]->CodonAt(msa.Width() - 2);
+    std::printf("ROWCHECK %s codons_equal=%d name_to_row=%d reads=%d unknown_throws=%d codonat0=%zu codonat_edge=%zu\n", name, codonsEqual,
+                byName, readsShared, unknownThrows, first.size(), last.size());
+    std::printf("ENDROWS\n");
+}
+
 int main()
 {
     // MSQ_TEST_COMM=1: the same run as the one rank of a "sharded" sample -- the library's RCCL communicator, the
@@ -154,6 +194,7 @@ int main()
         Dump("noconfig", aac);
         DumpPhase("noconfig", aac);
         DumpReports("noconfig", aac);
+        DumpRows("plain", aac.Rows(), true);
 
         Juliet::JulietSettings c;  // two genes in different frames + reference + DRMs + expected minors
         Juliet::DRM drm1{"drugA", {Juliet::DMutation('*', 11, '*')}};
@@ -211,6 +252,7 @@ int main()
         Dump("rich_default_subqv42", aac);
         DumpPhase("rich_default_subqv42", aac);
         DumpReports("rich_default_subqv42", aac);
+        DumpRows("rich", aac.Rows(), true);
     }
     // fuse (src/tools/Fuse.cpp:60-140): planted insertions -- in frame and strong, in frame but weaker and within 20
     // positions of a stronger one, out of frame, below half the coverage -- a majority deletion, noise; then too few reads
@@ -263,6 +305,7 @@ int main()
         std::printf("FUSE fuse%d 10 %s\n", n_reads, fuse10.ConsensusSequence().c_str());
         const Data::MSAByRow all(reads, Data::InsertionMode::All);  // what MSAColumn::Insertions() holds in the reference
         const Data::MSAByColumn cols(all);
+        DumpRows(("fuse" + std::to_string(n_reads)).c_str(), all, false);  // the plain-layout set is resident: no second pack
         int k = 0;
         for (const auto& c : cols) {
             if (!c.Insertions().empty()) {
@@ -272,6 +315,24 @@ int main()
             }
             ++k;
         }
+    }
+    {  // MSAColumn's result slots (include/pacbio/data/MSA.h:178-191, MSA.inl:82-112, src/MSA.cpp:223-237)
+        std::vector<Data::ArrayRead> two{Data::ArrayRead(0, "a", 0, 2, {Data::ArrayBase('=', 'A', 9), Data::ArrayBase('I', 'G', 9), Data::ArrayBase('=', 'C', 9)}),
+                                         Data::ArrayRead(1, "b", 0, 2, {Data::ArrayBase('D', '-', 0), Data::ArrayBase('I', 'T', 9), Data::ArrayBase('=', 'C', 9)})};
+        const Data::MSAByRow rows(two, Data::InsertionMode::All);
+        Data::MSAByColumn cols(rows);
+        Data::MSAColumn& col = cols[1];
+        std::cout << "COLUMN before " << col.PValue('A') << " " << col.PValue('-') << " " << col.SignificantInsertions().size() << " | " << cols[0] << "|\n";
+        Data::FisherResult f;
+        f.PValues = {{0.5, 0.25, 0.125, 1, 0.001, 1}};
+        f.Mask = {{0, 0, 0, 0, 1, 0}};
+        f.Hit = true;
+        f.ArgMax = 1;
+        col.AddFisherResult(f);
+        col.AddFisherResult(std::map<std::string, double>{{"G", 0.5}, {"T", 0.001}});
+        std::cout << "COLUMN after " << col.PValue('A') << " " << col.PValue('-') << " " << col.SignificantInsertions().size() << " "
+                  << col.SignificantInsertions().at(0) << " | ";
+        col.InDels(std::cout);
     }
     // exceptions keep the reference's types and texts
     try {

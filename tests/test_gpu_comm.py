@@ -68,6 +68,30 @@ def test_one_rank_collectives_are_identities(cx):
     other.close()
 
 
+def test_status_agreement(cx):
+    """msq_comm_agree_status (a rank that alone sees an error must not throw before the others know): with
+    the one rank there is, the status and its text go through the all-gather and come back as they went in; without a
+    communicator the call is the identity.  msq_comm_available is the local check ranks make before the collective
+    msq_comm_create."""
+    ctx, ex = cx
+    L = abi.lib()
+    assert L.msq_comm_available() == abi.MSQ_OK
+    agreed = C.c_int(99)
+    abi.check(L.msq_comm_agree_status(ctx.h, abi.MSQ_OK, None, C.byref(agreed)))
+    assert agreed.value == abi.MSQ_OK
+    abi.check(L.msq_comm_agree_status(ctx.h, abi.MSQ_ERR_CIGAR, b"Unexpected cigar 78", C.byref(agreed)))
+    assert agreed.value == abi.MSQ_ERR_CIGAR and L.msq_last_error() == b"Unexpected cigar 78"
+    # the text of the library's own last error when none is handed in
+    assert L.msq_comm_create(ctx.h, 0, 1, None) == abi.MSQ_ERR_ARG
+    text = L.msq_last_error()
+    abi.check(L.msq_comm_agree_status(ctx.h, abi.MSQ_ERR_ARG, None, C.byref(agreed)))
+    assert agreed.value == abi.MSQ_ERR_ARG and L.msq_last_error() == text and b"msq_comm_create" in text
+    other = device.Ctx(0)
+    abi.check(L.msq_comm_agree_status(other.h, abi.MSQ_ERR_BASE, b"Unexpected base", C.byref(agreed)))
+    assert agreed.value == abi.MSQ_ERR_BASE and L.msq_last_error() == b"Unexpected base"
+    other.close()
+
+
 def test_sharded_step_equals_plain_calls(cx):
     """Two shards of one sample pushed through the sharded step one after the other on the one rank there is, added up
     by hand where the all-reduce would add them: the global window and the whole sample's matrices and calls."""

@@ -21,14 +21,18 @@ ALPHA = float(np.float32(0.01))  # AminoAcidCaller.h:108
 
 
 @pytest.fixture(scope="module")
-def dump():
+def dump(tmp_path_factory):
     assert os.path.exists(BIN), "tests/cpp/front_test not built: run __graft_entry__.build()"
     env = dict(os.environ)
     for k in ("DELQV", "SUBQV", "INSQV", "QUALQV"):
         env.pop(k, None)
-    out = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env)
+    cwd = tmp_path_factory.mktemp("front")  # the expected-minors case writes validation.json into the working directory
+    out = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env, cwd=str(cwd))
     assert out.returncode == 0, out.stderr[-2000:]
     d = {"fisher": {}, "reads": {}, "cases": {}, "err": [], "ref": None, "phase": {}, "refx": None, "minors": []}
+    vj = os.path.join(str(cwd), "validation.json")
+    d["validation_json"] = open(vj).read() if os.path.exists(vj) else None
+    d["stderr"] = out.stderr
     cur_reads = cur_case = cur_phase = None
     d["json"], d["msatable"], d["errmode"] = {}, {}, {}
     block = None  # (kind, name, lines) while inside a JSON / MSATABLE / ERRMODE block
@@ -52,6 +56,20 @@ def dump():
             continue
         if t[0] == "INS":
             d.setdefault("ins", {}).setdefault(t[1], {})[int(t[2])] = {kv.split(":")[0]: int(kv.split(":")[1]) for kv in t[3:]}
+            continue
+        if t[0] == "ROWS":
+            cur_rows = d.setdefault("rows", {}).setdefault(t[1], {"n": int(t[2]), "W": int(t[3]), "rows": [], "check": None})
+            continue
+        if t[0] == "ROW":
+            cur_rows["rows"].append((t[2] if len(t) > 2 else "", {int(x.split(":")[0]): x.split(":")[1] for x in t[3:]}))
+            continue
+        if t[0] == "ROWCHECK":
+            cur_rows["check"] = dict(x.split("=") for x in t[2:])
+            continue
+        if t[0] == "ENDROWS":
+            continue
+        if t[0] == "COLUMN":
+            d.setdefault("column", {})[t[1]] = line[len("COLUMN " + t[1] + " "):]
             continue
         if t[0] == "PHASE":
             cur_phase = d["phase"].setdefault(t[1], {"vpos": [], "hit": [], "report": []})
@@ -105,9 +123,11 @@ def test_one_rank_communicator_changes_nothing():
     env = dict(os.environ)
     for k in ("DELQV", "SUBQV", "INSQV", "QUALQV"):
         env.pop(k, None)
-    plain = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env)
-    env["MSQ_TEST_COMM"] = "1"
-    comm = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env)
+    import tempfile
+    with tempfile.TemporaryDirectory() as cwd:  # validation.json lands in the working directory
+        plain = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env, cwd=cwd)
+        env["MSQ_TEST_COMM"] = "1"
+        comm = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env, cwd=cwd)
     assert plain.returncode == 0 and comm.returncode == 0, comm.stderr[-2000:]
     assert "communicator: rank 0 of 1" in comm.stderr
     keep = lambda text: [l for l in text.splitlines() if not l.startswith(("RCCL version", "HIP version", "ROCm version", "Hostname", "Librccl"))]
@@ -392,6 +412,59 @@ def test_fuse_consensus_and_insertion_maps(dump, name):
         assert cons == plain[:at] + "GGA" + plain[at:]
     else:
         assert len(m.fuse(50)) > 0 and len(dump["reads"][name]) < 50  # permissive mode: minCoverage 1
+
+
+@pytest.mark.parametrize("name", ["plain", "rich", "fuse400", "fuse30"])
+def test_rows_match_oracle(dump, name):
+    """MSAByRow::Rows() / NameToRow() / MSARow (include/pacbio/data/MSA.h:72-75,96-110; AddRead, src/MSA.cpp:144-186)
+    through the front -- the characters from msq_rows_decode over the packed reads in HBM, the insertion maps from the
+    insertion scan (over a set packed again in the plain layout for "plain" / "rich", over the resident one for the
+    fuse sets) -- against the oracle's rows and per-row insertion maps; parity unpinned like the pileup."""
+    got = dump["rows"][name]
+    rich = name == "rich"
+    m = orc.Msa(to_reads(dump["reads"][name], rich), (-1, -1, 42, -1))
+    want = m.rows()
+    assert (got["n"], got["W"]) == (want.shape[0], m.W) and len(got["rows"]) == want.shape[0]
+    n_ins = n_masked = 0
+    for r, (bases, ins) in enumerate(got["rows"]):
+        assert bases.replace("_", " ") == want[r].tobytes().decode(), r
+        # a run flushed behind the last column is an out-of-bounds write in the reference and dropped here (DESIGN 7, f4)
+        assert ins == {c: s for c, s in m.row_insertions(r).items() if c < m.W}, r
+        n_ins += len(ins)
+        n_masked += bases.count("N")
+    assert n_ins > 20
+    if rich:
+        assert n_masked > 1000  # SUBQV = 42 masks a tenth of the match bases: 'N' in the rows (src/MSA.cpp:163-166)
+    if name == "fuse400":  # the strings the packed form cannot hold come back whole: 69 bases, a non-ACGT character
+        assert any(len(s) == 69 for _, ins in got["rows"] for s in ins.values())
+        assert any("N" in s for _, ins in got["rows"] for s in ins.values())
+    chk = got["check"]
+    # CodingCodonAt over the rows == the MSA's own CodonsAt at every column (incl. -1, 0 and W); NameToRow finds every
+    # row and throws std::out_of_range otherwise; rows share the reads only in the shared_ptr constructor (MSA.cpp:101)
+    assert chk["codons_equal"] == "1" and chk["name_to_row"] == "1" and chk["reads"] == "1" and chk["unknown_throws"] == "1"
+    assert chk["codonat0"] == "2" and chk["codonat_edge"] == "2"  # CodonAt's i > 0 (MSA.cpp:193) and the right edge
+
+
+def test_validation_record_is_written(dump):
+    """With expected minors configured the caller writes validation.json into the working directory and the same
+    numbers to stderr (src/AminoAcidCaller.cpp:571-588, internal/AminoAcidCaller.inl:42-47): ostream formatting (6
+    significant digits) of the rates worked out from the TP / FP / FN / TN counts that test_caller_matches_oracle pins."""
+    c = dump["cases"]["expectedminors"]
+    tp, fp, fn, tn = c["perf"]
+    n_tests, n_minors = c["ntests"], len(dump["minors"])
+    g = lambda x: "%g" % x
+    want = ('{"true_positive_rate":%s,"false_positive_rate":%s,"num_tests":%s,"num_false_positives":%s,"accuracy":%s}' %
+            (g(tp / n_minors), g(fp / (n_tests - n_minors)), g(n_tests), g(fp), g((tp + tn) / (tp + fp + fn + tn))))
+    assert dump["validation_json"] == want
+    line = "%s %s %s %s %s" % (g(tp / n_minors), g(fp / (n_tests - n_minors)), g(n_tests), g((tp + tn) / (tp + fp + fn + tn)), g(fp))
+    assert line in dump["stderr"].splitlines()
+
+
+def test_column_result_slots(dump):
+    """MSAColumn::PValue / SignificantInsertions / AddFisherResult / InDels / operator<< (MSA.h:178-191, MSA.inl:82-112,
+    src/MSA.cpp:223-237): 1 until a result is attached, then what was attached."""
+    assert dump["column"]["before"] == "1 1 0 | 1\t0\t0\t0\t1\t|"
+    assert dump["column"]["after"] == "0.5 0.001 1 T | 2\t(-,0,0.001)\t(T,1,0.001)\t"
 
 
 def test_json_serializer_fixed_points(dump):

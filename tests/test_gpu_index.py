@@ -29,7 +29,7 @@ def host_index(p):
         g0, g1 = int(p["group_off"][r]), int(p["group_off"][r + 1])
         col = int(p["ref_start"][r])
         for g in range(g0, g1):
-            out[g] = ((col + 1) & 0x1fffffff) | ((r & 7) << 29)
+            out[g] = (0x1fffffff if (col < 0 or col + 1 > 0x1fffffff) else col + 1) | ((r & 7) << 29)  # saturates, never 0
             col += int(ncons[g])
     return out
 
@@ -135,3 +135,22 @@ def test_columns_beyond_the_index_range(ctx):
         assert abi.lib().msq_pileup_check(ctx.h) == abi.MSQ_ERR_WINDOW
     far = cases.make_reads([((1 << 29) + 10, "=" * 40, "ACGT" * 10), ((1 << 29) + 12, "=" * 30, "GTAC" * 7 + "GT")])
     both(ctx, device.pack_host(far), NONE)
+
+
+def test_negative_columns_never_yield_the_empty_word(ctx):
+    """a group whose first column is -1 (ReferenceStart -1, read index & 7 == 0) used to index as the word 0,
+    which the indexed kernels read as "lane past the batch" -- its bases vanished without the window error the
+    sum-and-walk path raises (the reference's assert(pos >= 0), src/MSA.cpp:149).  Negative columns saturate now."""
+    reads = cases.make_reads([(-1, "=" * 40, "ACGT" * 10), (3, "=" * 36, "ACGT" * 9)] + [(0, "=" * 40, "TGCA" * 10)] * 14)
+    packed = device.pack_host(reads)
+    idx = device.upload(packed, ctx.device, ctx=ctx)
+    ctx.sync()
+    got = idx.t["gcol"].cpu().numpy().view(np.uint32)
+    assert np.array_equal(got, host_index(packed)) and (got != 0).all() and (got[0] & 0x1fffffff) == 0x1fffffff
+    for with_ctx in (None, ctx):
+        dr = device.upload(packed, ctx.device, ctx=with_ctx)
+        nuc, codon = device.alloc_counts(ctx, 64)
+        abi.check(abi.lib().msq_pileup(ctx.h, dr.view, NONE, 0, 64, nuc.data_ptr(), codon.data_ptr(), abi.MSQ_PILEUP_STREAM))
+        assert abi.lib().msq_pileup_check(ctx.h) == abi.MSQ_ERR_WINDOW
+    # the window the reads themselves span (begin -1): no index is taken for a negative begin, counts as the simple kernel's
+    both(ctx, packed, NONE)

@@ -36,6 +36,79 @@ def test_shard_range_is_the_library_rule():
                 assert (f.value, c.value) == sharding.shard_range(n, r, world)
 
 
+def test_shard_by_base_count_is_the_library_rule_and_balances():
+    """msq_comm_shard_bases (host arithmetic): contiguous ranges that tile the reads, equal to the Python rule, and --
+    on hiv_1k's staggered reads, a tenth of them shortened -- closer to equal BASE counts than equal read counts are
+    ("balanced by base count via base_offset")."""
+    import ctypes as C
+    from minorseq_amd import abi
+    wl = synth.workload("hiv_1k", n_reads=1000)
+    reads = wl.host_reads(0, 1000)
+    sizes = np.diff(reads["base_off"]).astype(np.uint64)
+    # the worst case for equal read counts: the long reads first, short ones behind
+    for order in (np.arange(1000), np.argsort(-sizes.astype(np.int64), kind="stable")):
+        sz = sizes[order]
+        prefix = np.concatenate([[0], np.cumsum(sz)]).astype(np.uint64)
+        for world in (1, 2, 3, 8):
+            parts = []
+            for r in range(world):
+                f, c = C.c_uint64(), C.c_uint64()
+                abi.check(abi.lib().msq_comm_shard_bases(prefix.ctypes.data, 1000, r, world, C.byref(f), C.byref(c)))
+                assert (f.value, c.value) == sharding.shard_range_bases(prefix, r, world)
+                parts.append((f.value, c.value))
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == 1000
+            for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+                assert f0 + c0 == f1
+            by_bases = [int(prefix[f + c] - prefix[f]) for f, c in parts]
+            by_reads = [int(prefix[f + c] - prefix[f]) for f, c in (sharding.shard_range(1000, r, world) for r in range(world))]
+            assert max(by_bases) <= max(by_reads) + int(sz.max())
+            assert max(by_bases) - min(by_bases) <= 2 * int(sz.max())
+    # equal reads: the read-count rule up to one read
+    prefix = (np.arange(1001) * 2850).astype(np.uint64)
+    for world in (2, 3, 8):
+        for r in range(world):
+            f, c = sharding.shard_range_bases(prefix, r, world)
+            f0, c0 = sharding.shard_range(1000, r, world)
+            assert abs(f - f0) <= 1 and abs(c - c0) <= 1
+    # no reads, and more ranks than reads
+    f, c = C.c_uint64(7), C.c_uint64(7)
+    abi.check(abi.lib().msq_comm_shard_bases(None, 0, 0, 4, C.byref(f), C.byref(c)))
+    assert (f.value, c.value) == (0, 0)
+    prefix = np.array([0, 5, 9], dtype=np.uint64)
+    got = [sharding.shard_range_bases(prefix, r, 4) for r in range(4)]
+    assert sum(c for _, c in got) == 2 and all(c in (0, 1) for _, c in got)
+
+
+def test_bench_launcher_dry_run():
+    """`python bench.py --gpus N` (N > 1) without a launcher around it starts its own rank processes: the dry run prints
+    every child's command and environment -- one fresh interpreter per GPU, loopback rendezvous on a free port, the
+    same arguments -- and touches no GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "2", "--launch-dry-run"],
+                         capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    plan = json.loads(out.stdout.strip().splitlines()[-1])
+    ranks = plan["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1, 2, 3]
+    ports = {r["env"]["MASTER_PORT"] for r in ranks}
+    assert len(ports) == 1 and 1024 < int(ports.pop()) < 65536
+    for k, r in enumerate(ranks):
+        e = r["env"]
+        assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"]) == (str(k), str(k), "4", "127.0.0.1")
+        assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert r["argv"][0] == sys.executable
+        assert "--launch-dry-run" not in r["argv"] and r["argv"][-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # under a launcher's WORLD_SIZE the flag is an error, not a silent run
+    env2 = dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch-dry-run", "--cpu-sample", "0"],
+                         capture_output=True, text=True, timeout=120, env=env2)
+    assert bad.returncode != 0 and "launch-dry-run" in bad.stderr
+
+
 def _rank_main(rank, world, port, n_reads, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -46,6 +46,37 @@ def test_two_calls_in_a_row_second_smaller(ctx):
     assert torch.equal(n, wn) and torch.equal(c, wc)
 
 
+@pytest.mark.parametrize("qual", [-1, 40])
+def test_it_allocates_nothing(qual):
+    """The entry point's defining property, asserted: on a FRESH context (no msq_pileup before it, so nothing has grown
+    the context's scratch yet) a warm-up call loads the code object, then a second call leaves both the device's free
+    memory and the context's own allocations exactly as they were -- for the unmasked kernel and the QV-mask variant.
+    The counts are compared with msq_pileup's only afterwards (that call may allocate)."""
+    L = abi.lib()
+    c = device.Ctx(0)
+    try:
+        thr = abi.QvThresholds.make(qual=qual)
+        wl = synth.workload("pol_100k", n_reads=20000)
+        dr = device.synth_device(c, wl, 0, 20000)
+        nuc, codon = device.alloc_counts(c, wl.W)
+        abi.check(L.msq_pileup_noalloc(c.h, dr.view, thr, wl.win_begin0, wl.W, nuc.data_ptr(), codon.data_ptr()))  # warm-up
+        c.sync()
+        nuc.zero_()
+        codon.zero_()
+        torch.cuda.synchronize()
+        own0, free0 = L.msq_debug_ctx_device_bytes(c.h), torch.cuda.mem_get_info()[0]
+        abi.check(L.msq_pileup_noalloc(c.h, dr.view, thr, wl.win_begin0, wl.W, nuc.data_ptr(), codon.data_ptr()))
+        c.sync()
+        assert L.msq_debug_ctx_device_bytes(c.h) == own0
+        assert torch.cuda.mem_get_info()[0] == free0
+        abi.check(L.msq_pileup_check(c.h))
+        got_n, got_c = nuc.clone(), codon.clone()
+        wn, wc = device.pileup(c, dr, thr, wl.win_begin0, wl.W, mode=abi.MSQ_PILEUP_STREAM)
+        assert torch.equal(got_n, wn) and torch.equal(got_c, wc)
+    finally:
+        c.close()
+
+
 def test_accumulates_like_msq_pileup(ctx):
     thr = abi.QvThresholds.make()
     wl = synth.workload("pol_100k", n_reads=5000)
