@@ -61,6 +61,13 @@ def parse():
     ap.add_argument("--no-bake", action="store_true", help="with --qualqv: keep the QV plane and apply the threshold "
                     "inside every pileup pass instead of once at set-up (msq_reads_bake_qv)")
     ap.add_argument("--mode", default="auto", choices=["auto", "simple", "stream"])
+    ap.add_argument("--layout", default="auto", choices=["auto", "aligned", "normalized"], help="group layout of the resident reads: "
+                    "aligned = column space (msq_reads_align at set-up, like the packing: AddRead's placement done once; the pileup "
+                    "loads the words it counts), normalized = 32 consecutive bases per group + the group column index (the "
+                    "read-space kernel builds the rows in LDS in every pass); auto = aligned where its kernel applies (one "
+                    "column slab of <= 4032 columns, no QV plane read in the pass)")
+    ap.add_argument("--no-compare", action="store_true", help="default one-GPU line: do not also time the read-space kernel on the "
+                    "normalized layout of the same reads (`read_space_kernel`)")
     ap.add_argument("--window", default="known", choices=["known", "device", "host"], help="see the module docstring")
     ap.add_argument("--host-bounds", action="store_true", help="= --window host")
     ap.add_argument("--unfused", action="store_true", help="msq_pileup_begin + msq_pileup instead of msq_pileup_step")
@@ -105,6 +112,7 @@ def parse():
         a.h2d_steps = 3 if plain else 0
     if a.project_strong < 0:
         a.project_strong = 8 if plain else 0
+    a.compare = plain and not a.no_compare and a.layout == "auto"
     return a
 
 
@@ -264,7 +272,7 @@ def launch(a):
 class Run:
     """One shard resident in HBM with everything a step needs, and the timed loop over it."""
 
-    def __init__(self, a, ctx, ex, wl, first, reads, global_reads, window):
+    def __init__(self, a, ctx, ex, wl, first, reads, global_reads, window, layout=None):
         import torch
         from minorseq_amd import abi, device
         self.a, self.ctx, self.ex, self.wl, self.reads = a, ctx, ex, wl, reads
@@ -283,12 +291,26 @@ class Run:
             dr = device.bake_qv(ctx, src, self.thr)
             ctx.sync()
             del src
-        self.dr = dr
         if window is None:
             window = ex.allreduce_bounds(*device.window_bounds(ctx, dr))
         self.b0, self.e0 = window
         b0, W = self.b0, self.e0 - self.b0
         self.W = W
+        # the column-aligned layout (set-up, like the packing and the baking): on the word grid of the sample's window
+        unbaked_planes = (not self.baked) and (a.qualqv >= 0 or a.rich)
+        layout = a.layout if layout is None else layout
+        self.aligned = layout == "aligned" or (layout == "auto" and W <= 4032 and not unbaked_planes and a.mode == "auto" and
+                                               a.window != "device" and not (0 < a.slab_columns < W))
+        self.align_ms = None
+        if self.aligned:
+            ctx.sync()
+            t_al = time.perf_counter()
+            al = device.align(ctx, dr, self.thr, b0)
+            ctx.sync()
+            self.align_ms = (time.perf_counter() - t_al) * 1e3
+            self.n_bases = al.n_groups * 32
+            dr = al
+        self.dr = dr
         gb, ge = wl.gene_arrays()
         self.plan = device.Plan(ctx, gb, ge, wl.reference if wl.use_reference else "", b0 + 1, W)
         ctx.lfact_reserve(2 * global_reads + 2)
@@ -557,23 +579,55 @@ def main():
     pcie = None
     if a.h2d_steps > 0 and world == 1:  # the boundary handing over host buffers: packed reads cross PCIe every step
         dr = run.dr
-        # what crosses: the tables, the bit planes and the QV planes this run's thresholds read -- not the planes
-        # nobody looks at, and not the column index, which is derived data: rebuilt on the device after every copy
-        need = {"ref_start", "ref_end", "group_off", "bop"} | ({"qual"} if a.qualqv >= 0 else set()) | ({"subqv"} if a.rich else set())
-        host = {f: t.cpu().pin_memory() for f, t in dr.t.items() if t is not None and f in need}
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(a.h2d_steps):
-            for f, h in host.items():
-                dr.t[f].copy_(h, non_blocking=True)
-            if dr.t.get("gcol") is not None:
-                run.abi.check(run.L.msq_reads_index(ctx.h, dr.view, dr.t["gcol"].data_ptr()))
-            run.step()
-        barrier()
-        dt1 = (time.perf_counter() - t1) / a.h2d_steps
-        pcie = {"value": reads / dt1, "unit": "reads/s", "ms_per_step": dt1 * 1e3,
-                "host_bytes_per_step": int(sum(h.numel() * h.element_size() for h in host.values()))}
+        if run.aligned:
+            # the aligned set as the host would hold it: tables, the words, the guide (3 KB); nothing derived is rebuilt
+            v = dr.view
+            parts = [(v.ref_start, reads * 4), (v.ref_end, reads * 4), (v.group_off, (reads + 1) * 8), (v.bop, dr.n_groups * 16),
+                     (v.guide, int(v.guide_words) * 32)]
+            host = []
+            for addr, nbytes in parts:
+                h = torch.empty(max(nbytes, 1), dtype=torch.uint8).pin_memory()
+                run.abi.check(run.L.msq_memcpy_d2h(ctx.h, h.data_ptr(), addr, nbytes))
+                host.append((addr, h, nbytes))
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(a.h2d_steps):
+                for addr, h, nbytes in host:
+                    run.abi.check(run.L.msq_memcpy_h2d(ctx.h, addr, h.data_ptr(), nbytes))
+                run.step()
+            barrier()
+            dt1 = (time.perf_counter() - t1) / a.h2d_steps
+            host_bytes = int(sum(nb for _, _, nb in host))
+        else:
+            # what crosses: the tables, the bit planes and the QV planes this run's thresholds read -- not the planes
+            # nobody looks at, and not the column index, which is derived data: rebuilt on the device after every copy
+            need = {"ref_start", "ref_end", "group_off", "bop"} | ({"qual"} if a.qualqv >= 0 else set()) | ({"subqv"} if a.rich else set())
+            host = {f: t.cpu().pin_memory() for f, t in dr.t.items() if t is not None and f in need}
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(a.h2d_steps):
+                for f, h in host.items():
+                    dr.t[f].copy_(h, non_blocking=True)
+                if dr.t.get("gcol") is not None:
+                    run.abi.check(run.L.msq_reads_index(ctx.h, dr.view, dr.t["gcol"].data_ptr()))
+                run.step()
+            barrier()
+            dt1 = (time.perf_counter() - t1) / a.h2d_steps
+            host_bytes = int(sum(h.numel() * h.element_size() for h in host.values()))
+        pcie = {"value": reads / dt1, "unit": "reads/s", "ms_per_step": dt1 * 1e3, "host_bytes_per_step": host_bytes}
         del host
+
+    # the same reads in the normalized layout through the read-space kernel (the dominant kernel of rounds 1 and 2), same run
+    compare = None
+    if a.compare and world == 1 and run.aligned:
+        try:
+            run0 = Run(a, ctx, ex, wl, 0, reads, reads, (run.b0, run.e0), layout="normalized")
+            dt0, k0_ms, p0_ms, _ = run0.timed(barrier)
+            compare = {"layout": "normalized groups + group column index (0.625 B/base streamed); rows built in LDS in every pass",
+                       "ms_per_step": dt0 / a.steps * 1e3, "value": reads / (dt0 / a.steps), "unit": "reads/s", "kernel_ms": k0_ms, "path_ms": p0_ms}
+            del run0
+        except Exception as e:  # noqa: BLE001 -- the line says why the comparison is missing
+            compare = {"error": "%s: %s" % (type(e).__name__, e)}
 
     projection = None
     if a.project_strong > 1 and world == 1:
@@ -611,15 +665,19 @@ def main():
         # what the kernel really streams: 16 B of bit planes per 32-base group, 32 B per group for every QV plane a
         # threshold makes it read, 12 B of tables per read (the QV planes of an unmasked or baked set are never touched)
         # + 4 B per group of column index when the set carries one and the kernel variant uses it (no QV planes to read)
-        indexed = bool(run.dr.view.gcol) and (baked or planes == 0) and a.mode != "simple"
-        real_bytes = n_bases / 32 * (16 + 32 * (0 if baked else planes) + (4 if indexed else 0)) + 12.0 * shard_reads
-        kernel_name = "pileup_simple_kernel" if a.mode == "simple" else "pileup_kernel"
+        aligned = run.aligned
+        indexed = (not aligned) and bool(run.dr.view.gcol) and (baked or planes == 0) and a.mode != "simple"
+        real_bytes = n_bases / 32 * (16 + 32 * (0 if (baked or aligned) else planes) + (4 if indexed else 0)) + (20.0 if aligned else 12.0) * shard_reads
+        kernel_name = "pileup_simple_kernel" if a.mode == "simple" else "pileup_rows_kernel" if aligned else "pileup_kernel"
         traffic = None if (a.rich or a.scaling == "strong" and world > 1) else load_traffic(kernel_name, wl.name, shard_reads, a.qualqv, baked)
         physical = (traffic or real_bytes) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         limiter = "valu/latency" if physical < 0.8 * 6300.0 else "hbm"
         # a leaner format than 1.5 B/base may exceed frac 1 only by reading less -- state the format
         qv_read = 0 if baked else planes
-        fmt = "0.5 B/base bit planes (2-bit nucleotide + 2-bit op, sliced per 32-base group)" + \
+        fmt = ("column-aligned groups (msq_reads_align at set-up: a group = a 32-column word of its read's row, 2-bit nucleotide + 2-bit op "
+               "per column, inserted bases left out): 0.5 B per column-consuming base + 20 B/read of tables; no QV plane, no column index "
+               "read; algorithmic bytes price 1.5 B/base as SURVEY 8d states them") if aligned else \
+              "0.5 B/base bit planes (2-bit nucleotide + 2-bit op, sliced per 32-base group)" + \
               (" + 0.125 B/base group column index" if indexed else "") + " + 12 B/read; " + \
               ("%d QV plane%s read in the pass (1 B/base each)" % (qv_read, "" if qv_read == 1 else "s") if qv_read else
                "QV planes not read: " + ("thresholds applied at pack time" if baked else "QUALQV unset, no threshold can mask a base")) + \
@@ -648,7 +706,8 @@ def main():
                             if multi else "none (one GPU)",
                 "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 127) // 128),
                 "pileup_launches_per_step": run.launches_per_step,
-                "read_layout": "column-slab partition (built at set-up)" if n_slabs else "one read set",
+                "read_layout": ("column-slab partition (built at set-up)" if n_slabs else
+                                "one read set, column-aligned (msq_reads_align at set-up: %.1f ms)" % run.align_ms if aligned else "one read set, normalized groups"),
                 "qv_thresholds": "unset" if a.qualqv < 0 and not a.rich else "applied at pack time (baked; the bake pass is set-up, not timed)" if baked else "applied in every pass",
                 "clock_spinup": ("%d untimed steps (%.0f ms) at the end of set-up, before the warm-up steps" % (run.spinup_steps, a.spinup_ms)
                                  if run.spinup_steps else "none"),
@@ -680,6 +739,8 @@ def main():
             out["pcie_inclusive"] = pcie
         if projection is not None:
             out["strong_projection"] = projection
+        if compare is not None:
+            out["read_space_kernel"] = compare
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     ex.close()

@@ -91,8 +91,11 @@ typedef struct msq_packed_reads {
     const uint8_t* subqv;       /* [n_groups*32] or NULL */
     const uint8_t* insqv;       /* [n_groups*32] or NULL */
     uint32_t flags;             /* MSQ_READS_* */
-    uint32_t reserved;
+    int32_t align_origin;       /* MSQ_READS_ALIGNED: the reference column the groups are aligned to (else 0) */
     const uint32_t* gcol;       /* [n_groups] or NULL: the group column index (msq_reads_index) */
+    const uint32_t* guide;      /* [guide_words][8] or NULL: the set's guide / alt haplotype (msq_reads_align) */
+    uint32_t guide_words;
+    uint32_t reserved;
 } msq_packed_reads;
 
 #define MSQ_READS_HAS_EXOTIC 1u /* some base uses op 1 with nucleotide code 2 or 3 */
@@ -102,6 +105,12 @@ typedef struct msq_packed_reads {
 #define MSQ_READS_QV_BAKED 8u   /* made by msq_reads_bake_qv: QV-failing match bases already read 'N', no QV planes */
 #define MSQ_READS_INS_EXOTIC 16u /* some inserted ('I') base is not ACGT: it was packed as 'A'; insertion strings taken from
                                    the packed planes differ from the reference's there (see msq_insertion.read / first_base) */
+
+#define MSQ_READS_ALIGNED 32u    /* made by msq_reads_align: group k of a read holds exactly the reference columns
+                                   [align_origin + 32 (a + k), + 32), a = (ReferenceStart - align_origin) >> 5, the base of
+                                   column c in slot c & 31; slots without a base are padding (op 3); inserted bases are
+                                   left out (nothing on the pileup / phasing path reads them, src/MSA.cpp:172-174).  Still a
+                                   valid plain-layout set for every other call */
 
 /* The group column index of a packed set in HBM: gcol[g] = (reference column of group g's first column-consuming
  * base + 1) | (index of its read & 7) << 29 -- `pos` of MSAByRow::AddRead (src/MSA.cpp:148,172-176) at the group's first
@@ -143,6 +152,24 @@ int msq_packed_dev_free(msq_ctx* ctx, msq_packed_dev* p);
  * under `thr`, bit for bit, from 0.5 instead of 1.5 .. 4.5 bytes per base.  The thresholds of a juliet run are
  * fixed before the reads are loaded (JulietSettings), so the front bakes right after packing.  Asynchronous. */
 int msq_reads_bake_qv(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, msq_packed_dev** out);
+
+/* The column-aligned layout: MSAByRow::AddRead's placement (`row.Bases[pos++]`, src/MSA.cpp:148,158-171) done ONCE, when
+ * the set is made, instead of in every pass over it.  In the other layouts a group holds 32 consecutive BASES of its
+ * read, so where its bases land in the row depends on every insertion before it: each pass finds the columns again
+ * (a prefix sum or the column index), shifts every group's planes to its bit offset and ORs them into a row in LDS.
+ * Here a group IS a 32-column word of the read's row (still 2 bits of nucleotide + 2 bits of op per base, 16 bytes per
+ * group), so the pileup needs no row building at all: a lane loads the word it counts.  `origin` fixes the word grid:
+ * the pileup takes the fast kernel when its window begins a multiple of 32 columns from it -- pass the window's first
+ * column (the reads' common ReferenceStart for an amplicon; on a sharded sample the GLOBAL window begin); origin <=
+ * every ReferenceStart.  Thresholds are applied as in msq_reads_bake_qv (the result carries no QV planes).  The set
+ * also carries a GUIDE: per column the majority base and -- where at least max(3, sample / 256) sampled reads agree on
+ * another base -- a runner-up, learnt from up to 2048 reads spread evenly over the set (guide[w] = {valid, bit 0,
+ * bit 1, 0, valid, alt bit 0, alt bit 1, has alt} for columns [origin + 32 w, + 32)).  A speed hint only: the pileup
+ * counts cells that match the guide in registers, cells that match the alt haplotype in LDS and everything else with
+ * global atomics; any guide gives the same counts.  The new set is independent of the source (the caller keeps and
+ * frees that).  Synchronises. */
+int msq_reads_align(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t origin,
+                    msq_packed_dev** out);
 
 /* One ArrayBase (include/pacbio/data/ArrayRead.h:96-119) as an 8-byte record: the boost::optional QVs become a
  * presence byte + value.  has_qual covers qual; has_rich covers del, sub and ins (ArrayRead.h:98-101 sets all
@@ -246,7 +273,8 @@ int msq_pileup_step(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_
  * accumulate shards.  d_reads fields are device pointers.  Async. */
 #define MSQ_PILEUP_AUTO 0     /* pick the kernel */
 #define MSQ_PILEUP_SIMPLE 1   /* force the simple per-read kernel (any width, any op) */
-#define MSQ_PILEUP_STREAM 2   /* force the streaming bit-plane kernel (error if not applicable) */
+#define MSQ_PILEUP_STREAM 2   /* force a streaming bit-plane kernel (error if not applicable) */
+#define MSQ_PILEUP_ROWS 3     /* force the kernel over column-aligned sets (msq_reads_align; error if not applicable) */
 int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
                int32_t W, uint32_t* d_nuc, uint32_t* d_codon, int mode);
 /* msq_pileup whose window comes from device memory, as msq_window_bounds_device (and a MAX all-reduce) left it:

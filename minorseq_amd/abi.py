@@ -13,12 +13,13 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("MSQ_LIB_DIR", "lib"), "libmsq_hip
 MSQ_OK = 0
 MSQ_ERR_ARG, MSQ_ERR_HIP, MSQ_ERR_CIGAR, MSQ_ERR_BASE = -1, -2, -3, -4
 MSQ_ERR_WINDOW, MSQ_ERR_RANGE, MSQ_ERR_NODEVICE, MSQ_ERR_NOMEM = -5, -6, -7, -8
-MSQ_PILEUP_AUTO, MSQ_PILEUP_SIMPLE, MSQ_PILEUP_STREAM = 0, 1, 2
+MSQ_PILEUP_AUTO, MSQ_PILEUP_SIMPLE, MSQ_PILEUP_STREAM, MSQ_PILEUP_ROWS = 0, 1, 2, 3
 MSQ_READS_HAS_EXOTIC = 1
 MSQ_READS_NORMALIZED = 2
 MSQ_READS_PAD_MARKED = 4
 MSQ_READS_QV_BAKED = 8
 MSQ_READS_INS_EXOTIC = 16
+MSQ_READS_ALIGNED = 32
 MSQ_PACK_PLAIN = 1
 MSQ_COMM_ID_BYTES = 128
 
@@ -42,8 +43,11 @@ class PackedReads(C.Structure):
         ("subqv", C.c_void_p),
         ("insqv", C.c_void_p),
         ("flags", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("align_origin", C.c_int32),
         ("gcol", C.c_void_p),
+        ("guide", C.c_void_p),
+        ("guide_words", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -102,6 +106,7 @@ _SIGNATURES = {
     "msq_packed_dev_view": (C.POINTER(PackedReads), [_P]),
     "msq_reads_bake_qv": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.POINTER(_P)]),
     "msq_packed_dev_free": (C.c_int, [_P, _P]),
+    "msq_reads_align": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.POINTER(_P)]),
     "msq_pack_reads_device": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(_P)]),
     "msq_pack_reads_device_fill": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(_P)]),
     "msq_pack_reads_device_baked": (C.c_int, [_P, C.c_uint64, _P, _P, _P, _P, C.c_uint32, C.c_int, C.c_int64, C.POINTER(QvThresholds), C.POINTER(_P)]),

@@ -59,8 +59,8 @@ struct msq_ctx {
 // Packed reads resident in HBM and owned by the library: the eight arrays of msq_packed_reads (ref_start, ref_end,
 // group_off, bop, qual, delqv, subqv, insqv; absent planes NULL) and the view over them.
 struct msq_packed_dev {
-    void* ptrs[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [8]: the group column index
-    msq_packed_reads view;
+    void* ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [8]: the group column index, [9]: the guide
+    msq_packed_reads view = {};
 };
 
 // Record the begin / end event of the next timing slot (no-ops when timing is off or the slots are used up).

@@ -13,7 +13,7 @@ struct msq_packed_host {
     std::vector<uint64_t> group_off;
     std::vector<uint32_t> bop;
     std::vector<uint8_t> qual, delqv, subqv, insqv;
-    msq_packed_reads view;
+    msq_packed_reads view = {};
 };
 
 
@@ -129,7 +129,7 @@ extern "C" int msq_pack_reads(uint64_t n_reads, const int32_t* ref_start, const 
         v.subqv = subqv ? p->subqv.data() : nullptr;
         v.insqv = insqv ? p->insqv.data() : nullptr;
         v.flags = (exotic ? MSQ_READS_HAS_EXOTIC : 0u) | (ins_exotic ? MSQ_READS_INS_EXOTIC : 0u) | MSQ_READS_NORMALIZED;
-        v.reserved = 0;
+        v.align_origin = 0;
     } catch (const std::bad_alloc&) {
         delete p;
         return msq_fail(MSQ_ERR_NOMEM, "msq_pack_reads: out of memory");
@@ -161,7 +161,7 @@ extern "C" int msq_reads_upload(msq_ctx* ctx, const msq_packed_reads* h, msq_pac
         if (e == hipSuccess && bytes[k])
             e = hipMemcpyAsync(d->ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
-            for (int j = 0; j < 9; ++j)
+            for (int j = 0; j < 10; ++j)
                 if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
             delete d;
             return msq_fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "msq_reads_upload: %s",
@@ -178,9 +178,11 @@ extern "C" int msq_reads_upload(msq_ctx* ctx, const msq_packed_reads* h, msq_pac
     d->view.subqv = (const uint8_t*)d->ptrs[6];
     d->view.insqv = (const uint8_t*)d->ptrs[7];
     d->view.gcol = nullptr;
+    d->view.guide = nullptr;  // a host view's guide (if any) is a host pointer: not carried over
+    d->view.guide_words = 0;
     if (int rc = msq_packed_dev_index(ctx, d)) {  // the group column index, derived on the device
         (void)hipStreamSynchronize(ctx->stream);
-        for (int j = 0; j < 9; ++j)
+        for (int j = 0; j < 10; ++j)
             if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
         delete d;
         return rc;
@@ -196,7 +198,7 @@ extern "C" int msq_packed_dev_free(msq_ctx* ctx, msq_packed_dev* p)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    for (int j = 0; j < 9; ++j)
+    for (int j = 0; j < 10; ++j)
         if (p->ptrs[j]) (void)hipFree(p->ptrs[j]);
     delete p;
     return MSQ_OK;
@@ -359,7 +361,7 @@ static uint64_t compact_records(uint8_t* dst, const void* src, int64_t n, const 
 
 static void free_packed_dev(msq_packed_dev* d)
 {
-    for (int j = 0; j < 9; ++j)
+    for (int j = 0; j < 10; ++j)
         if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
     delete d;
 }
@@ -646,7 +648,7 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
         const bool has_q = ((any_all >> 16) & 0xff) != 0, has_r = ((any_all >> 24) & 0xff) != 0;
         if ((thr.qual >= 0 && has_q) || (has_r && (thr.del >= 0 || thr.sub >= 0 || thr.ins >= 0))) v.flags |= MSQ_READS_QV_BAKED;
     }
-    v.reserved = 0;
+    v.align_origin = 0;
     v.gcol = nullptr;
     if (int rc2 = msq_packed_dev_index(ctx, d)) {
         (void)hipStreamSynchronize(ctx->stream);

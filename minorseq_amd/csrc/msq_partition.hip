@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void slab_gather_kernel(const uint64_t* __rest
 void free_set(msq_packed_dev* d)
 {
     if (!d) return;
-    for (int j = 0; j < 9; ++j)
+    for (int j = 0; j < 10; ++j)
         if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
     delete d;
 }
@@ -249,8 +249,8 @@ extern "C" int msq_reads_partition(msq_ctx* ctx, const msq_packed_reads* d_reads
         v.delqv = (const uint8_t*)d->ptrs[5];
         v.subqv = (const uint8_t*)d->ptrs[6];
         v.insqv = (const uint8_t*)d->ptrs[7];
-        v.flags = d_reads->flags;
-        v.reserved = 0;
+        v.flags = d_reads->flags & ~MSQ_READS_ALIGNED;  // a slab's pieces are plain groups to every kernel
+        v.align_origin = 0;
         v.gcol = nullptr;
         if (msq_packed_dev_index(ctx, d) != MSQ_OK) return fail(MSQ_ERR_HIP, "group column index", hipGetLastError());  // a sub-read is a read
     }

@@ -12,6 +12,9 @@
 int msq_pileup_stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr,
                              int32_t win_begin0, int32_t W, const int32_t* d_bounds, uint32_t* d_nuc, uint32_t* d_codon,
                              bool* handled);
+int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
+                           uint32_t* d_nuc, uint32_t* d_codon, uint32_t* fixed_partials, size_t fixed_bytes, int32_t* d_step_bounds,
+                           uint32_t* d_dev, bool* handled);
 int msq_pileup_stream_step_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_thresholds& thr, int32_t win_begin0, int32_t W,
                                   int32_t* d_bounds, uint32_t* d_counts, bool* handled);
 
@@ -290,7 +293,14 @@ extern "C" int msq_pileup(msq_ctx* ctx, const msq_packed_reads* d_reads, const m
     MSQ_HIP(hipSetDevice(ctx->device));
     if (mode != MSQ_PILEUP_SIMPLE) {
         bool handled = false;
-        int rc = msq_pileup_stream_launch(ctx, *d_reads, *thr, win_begin0, W, nullptr, d_nuc, d_codon, &handled);
+        // MSQ_PILEUP_ROWS: only the kernel over column-aligned sets (tests ask for it by name; AUTO and STREAM try it first)
+        int rc = msq_pileup_rows_launch(ctx, *d_reads, *thr, win_begin0, W, d_nuc, d_codon, nullptr, 0, nullptr, nullptr, &handled);
+        if (rc != MSQ_OK) return rc;
+        if (handled) return MSQ_OK;
+        if (mode == MSQ_PILEUP_ROWS)
+            return msq_fail(MSQ_ERR_ARG, "msq_pileup: the aligned-set kernel is not applicable (flags=%u, W=%d, origin %d)", d_reads->flags, W,
+                            d_reads->align_origin);
+        rc = msq_pileup_stream_launch(ctx, *d_reads, *thr, win_begin0, W, nullptr, d_nuc, d_codon, &handled);
         if (rc != MSQ_OK) return rc;
         if (handled) return MSQ_OK;
         if (mode == MSQ_PILEUP_STREAM)

@@ -183,7 +183,8 @@ class LibReads:
         return {"n_reads": n, "n_groups": g, "ref_start": back(v.ref_start, np.int32, n), "ref_end": back(v.ref_end, np.int32, n),
                 "group_off": back(v.group_off, np.uint64, n + 1), "bop": back(v.bop, np.uint32, g * 4),
                 "qual": back(v.qual, np.uint8, g * 32), "delqv": back(v.delqv, np.uint8, g * 32),
-                "subqv": back(v.subqv, np.uint8, g * 32), "insqv": back(v.insqv, np.uint8, g * 32), "flags": self.flags}
+                "subqv": back(v.subqv, np.uint8, g * 32), "insqv": back(v.insqv, np.uint8, g * 32), "flags": self.flags,
+                "align_origin": int(v.align_origin), "guide": back(v.guide, np.uint32, int(v.guide_words) * 8)}
 
     def close(self):
         if self.handle is not None:
@@ -201,6 +202,16 @@ def bake_qv(ctx, dr, thr):
     """msq_reads_bake_qv: the set with the thresholds applied (QV-failing match bases read 'N', no QV planes)."""
     h = C.c_void_p()
     abi.check(abi.lib().msq_reads_bake_qv(ctx.h, dr.view, thr, C.byref(h)))
+    return LibReads(ctx, h)
+
+
+def align(ctx, dr, thr=None, origin=None):
+    """msq_reads_align: the set re-laid in column space (MSQ_READS_ALIGNED) on the word grid of `origin` (default: the
+    reads' window begin), thresholds applied, with its guide."""
+    if origin is None:
+        origin = window_bounds(ctx, dr)[0] if dr.n_reads else 0
+    h = C.c_void_p()
+    abi.check(abi.lib().msq_reads_align(ctx.h, dr.view, thr if thr is not None else abi.QvThresholds.make(), int(origin), C.byref(h)))
     return LibReads(ctx, h)
 
 
