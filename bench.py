@@ -64,8 +64,8 @@ def parse():
     ap.add_argument("--layout", default="auto", choices=["auto", "aligned", "normalized"], help="group layout of the resident reads: "
                     "aligned = column space (msq_reads_align at set-up, like the packing: AddRead's placement done once; the pileup "
                     "loads the words it counts), normalized = 32 consecutive bases per group + the group column index (the "
-                    "read-space kernel builds the rows in LDS in every pass); auto = aligned where its kernel applies (one "
-                    "column slab of <= 4032 columns, no QV plane read in the pass)")
+                    "read-space kernel builds the rows in LDS in every pass); auto = aligned where its kernel applies (no QV "
+                    "plane read in the pass)")
     ap.add_argument("--no-compare", action="store_true", help="default one-GPU line: do not also time the read-space kernel on the "
                     "normalized layout of the same reads (`read_space_kernel`)")
     ap.add_argument("--window", default="known", choices=["known", "device", "host"], help="see the module docstring")
@@ -299,8 +299,8 @@ class Run:
         # the column-aligned layout (set-up, like the packing and the baking): on the word grid of the sample's window
         unbaked_planes = (not self.baked) and (a.qualqv >= 0 or a.rich)
         layout = a.layout if layout is None else layout
-        self.aligned = layout == "aligned" or (layout == "auto" and W <= 4032 and not unbaked_planes and a.mode == "auto" and
-                                               a.window != "device" and not (0 < a.slab_columns < W))
+        self.aligned = layout == "aligned" or (layout == "auto" and not unbaked_planes and a.mode == "auto" and
+                                               a.window != "device" and not a.slab_columns and not a.no_partition)
         self.align_ms = None
         if self.aligned:
             ctx.sync()
@@ -322,7 +322,7 @@ class Run:
         # windows wider than one slab of the streaming kernel: the reads are laid out per column slab at set-up (pack
         # time, untimed like the packing itself), so that every slab launch streams only its share of the reads
         self.part = None
-        if (W > 4096 or 0 < a.slab_columns < W) and not a.no_partition and a.mode != "simple":
+        if (W > 4096 or 0 < a.slab_columns < W) and not a.no_partition and a.mode != "simple" and not self.aligned:
             self.part = device.Partition(ctx, dr, b0, W, a.slab_columns)
         self.launches_per_step = 1  # timing records per step: counted before the timed steps (run)
         self.flow = "host" if (a.window == "host" or (a.mode == "simple" and a.window == "device")) else a.window
@@ -704,7 +704,7 @@ def main():
                 "exchange": (ex_note or (("one RCCL group per step (bounds MAX + counts SUM)" if flow == "known" else "two RCCL all-reduces per step")
                                           + ", library communicator (msq_comm_*) of %d rank%s as RCCL reports it" % (comm_ranks, "" if comm_ranks == 1 else "s")))
                             if multi else "none (one GPU)",
-                "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 127) // 128),
+                "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 125) // 126 if run.aligned else (((W + 31) // 32) + 127) // 128),
                 "pileup_launches_per_step": run.launches_per_step,
                 "read_layout": ("column-slab partition (built at set-up)" if n_slabs else
                                 "one read set, column-aligned (msq_reads_align at set-up: %.1f ms)" % run.align_ms if aligned else "one read set, normalized groups"),

@@ -26,10 +26,11 @@
 
 namespace {
 
-constexpr int kRowsWaves = 8;     // waves per workgroup (one workgroup per CU, 2 waves per SIMD)
-constexpr int kQueueCap = 512;    // entries of a wave's deviation queue: 16 B of planes + a 4-byte tag each
-constexpr int kQueueDrainAt = 64; // at the end of a batch: drain when at least this many entries wait (a full wave of lanes)
-constexpr int kLanesPerPass = 63; // productive lanes of a pass; lane 63 lends the next word
+constexpr int kRowsWaves = 12;     // waves per workgroup (one workgroup per CU, 3 waves per SIMD: 168 VGPRs, nothing spills)
+constexpr int kQueueCap = 384;     // entries of a wave's deviation queue: 16 B of planes + a 4-byte tag each
+constexpr int kQueueRoom = 128;    // two reads add at most this many entries: drained when fewer slots are left
+constexpr int kQueueDrainAt = 64;  // at the end of a batch: drain when at least this many entries wait (a full wave of lanes)
+constexpr int kLanesPerPass = 63;  // productive lanes of a wave; lane 63 lends the next word
 
 struct RowsArgs {
     const int32_t* ref_start;
@@ -42,32 +43,33 @@ struct RowsArgs {
     int32_t win_begin0, W;
     int32_t origin;   // the set's align origin
     int32_t word0;    // grid word of window word 0: (win_begin0 - origin) / 32
-    int32_t G;        // words of the window
+    int32_t G;        // words of this launch's column slab (<= 126)
+    int32_t slab_w0;  // window word of the slab's word 0
+    int32_t Gtot;     // words of the window
+    int32_t n_roles;  // 1: every wave counts words 0 .. 62; 2: the waves of role 1 count words 63 .. 125
     uint32_t flush_wide;
     uint32_t* nuc;    // where deviations go (the caller's matrices, or the context's deviation matrix in a fused step)
     uint32_t* codon;
-    uint32_t* partials;  // [workgroups][NC + 4][G * 32]
+    uint32_t* partials;  // [workgroups][NC + 6][G * 32]
     uint32_t* err;
     uint32_t* bounds_acc;  // msq_pileup_step: the shard's bounds come out of this launch too (NULL otherwise)
     int32_t* bounds_out;
 };
 
-typedef const uint64_t __attribute__((address_space(4))) * c_u64_ptr;
-typedef const int32_t __attribute__((address_space(4))) * c_i32_ptr;
-
 __device__ __forceinline__ uint32_t dpp_next_lane(uint32_t v)  // lane i <- lane i + 1, lane 63 <- 0 (wave_shl:1)
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
-// One read of a batch as the loads see it: its buffer resource and where it sits relative to the window.
-struct RowDesc {
-    uint64_t base;  // address of its first group
-    uint32_t ng;    // its groups = words of its row (0: no such read)
-    int32_t rel;    // window word of its first group
+// The eight reads of a batch as the loads need them, lane i = read i: the first three words of the read's buffer
+// resource (base address, records = its groups in bytes) and the byte offset of window word 0 inside the read.
+struct RowTable {
+    uint32_t w0, w1, nb;
+    int32_t rel16;
 };
 
-template <int PASSES, bool MANY_N>
+template <bool MANY_N>
 __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a)
 {
     constexpr int NC = MANY_N ? 4 : 3;
@@ -77,26 +79,34 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
     const int wave = (int)uni((uint32_t)tid >> 6);
     const int G = a.G, W = a.W;
     const uint32_t wg = blockIdx.x, nwg = gridDim.x;
-    // LDS: per wave a deviation queue (planes, then tags); the batch counter; guide and alt haplotype words of the window
+    // a wave counts ONE 63-word range of the window: role 0 words 0 .. 62, role 1 words 63 .. 125 (windows of more than 63
+    // words: the waves alternate).  Every role sees every batch of the workgroup.
+    const int n_roles = a.n_roles;
+    const int role = n_roles == 2 ? (wave & 1) : 0, wave_in_role = n_roles == 2 ? (wave >> 1) : wave, waves_per_role = NWV / n_roles;
+    // LDS: per wave a deviation queue (planes, then tags); the batch counters; guide and alt haplotype words of the window
     // [G + 2][4] each; one alt counter per window column
     uint4* const q4 = reinterpret_cast<uint4*>(lds + (size_t)wave * (kQueueCap * 5));
     uint32_t* const qt = reinterpret_cast<uint32_t*>(q4 + kQueueCap);
-    uint32_t* const draw_ctr = lds + (size_t)NWV * (kQueueCap * 5);
+    uint32_t* const draw_ctr = lds + (size_t)NWV * (kQueueCap * 5);  // [0], [1]: the roles' batch counters; [2], [3]: the bounds
     uint32_t* const gl = draw_ctr + 4;
     uint32_t* const gl2 = gl + 4 * (G + 2);
     uint32_t* const altc = gl2 + 4 * (G + 2);  // [G * 32]: alt nucleotide count | alt codon count << 16
+    // isolated substitutions per column, by the rank r of the base read ((guide's code + 1 + r) & 3): [G * 32] r0 | r1 << 16,
+    // then [G * 32] r2 (a workgroup sees < 65536 reads)
+    uint32_t* const subA = altc + G * 32;
+    uint32_t* const subB = subA + G * 32;
     uint32_t my_err = 0;
 
     // ---- set-up: the guide words of the window from the set's guide (grid word = window word + word0)
     if (tid < 4) draw_ctr[tid] = 0;
     for (int i = tid; i < (G + 2) * 4; i += T) {
         const int w = i >> 2, k = i & 3;
-        const long long gw = (long long)a.word0 + w;
-        const bool in = w < G && gw >= 0 && gw < (long long)a.guide_words;
+        const long long gw = (long long)a.word0 + a.slab_w0 + w;  // words G, G + 1: the next slab's first words, or nothing
+        const bool in = a.slab_w0 + w < a.Gtot && gw >= 0 && gw < (long long)a.guide_words;
         gl[i] = in ? a.guide[(size_t)gw * 8 + k] : 0u;
         gl2[i] = in ? a.guide[(size_t)gw * 8 + 4 + k] : 0u;
     }
-    for (int i = tid; i < G * 32; i += T) altc[i] = 0;
+    for (int i = tid; i < 3 * G * 32; i += T) altc[i] = 0;  // alt counters and both substitution tables
     // (msq_pileup_step) this workgroup's share of the shard's reads for the window bounds
     int32_t b_lo = INT32_MAX, b_hi = INT32_MIN;
     const bool with_bounds = a.bounds_acc != nullptr;
@@ -109,91 +119,75 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
     }
     __syncthreads();
 
-    // ---- this lane's words: pass p, lane L <-> window word 63 p + L; lanes 0 .. 62 count, lane 63 lends its word
-    int cgp[PASSES];
-    bool act[PASSES];
-    uint32_t ccols[PASSES], tail[PASSES], gx[PASSES], gy[PASSES], gz[PASSES], seen[PASSES];
-    uint64_t actb[PASSES];
-    uint32_t cnt[PASSES][NC][kLevels];
+    // ---- this lane's word: lanes 0 .. 62 count, lane 63 lends its word to lane 62
+    const int lw = kLanesPerPass * role + lane;  // word of the slab
+    const int cg = a.slab_w0 + lw;               // word of the window
+    const bool act = lane < kLanesPerPass && lw < G;
+    const uint32_t ccols = act ? codon_cols_of(cg, W) : 0u;
+    const uint64_t actb = uni64(__ballot(act));
+    // columns of this word at or beyond W: a base there is outside the window (the reference writes past the row)
+    const int over = W - cg * 32;
+    const uint32_t tail = act ? (over >= 32 ? 0u : over <= 0 ? 0xffffffffu : (0xffffffffu << over)) : 0u;
+    const int gw_ = min(lw, G + 1);
+    const uint32_t gx = gl[gw_ * 4], gy = gl[gw_ * 4 + 1], gz = gl[gw_ * 4 + 2];
+    const int32_t lw16 = cg << 4;
+    uint32_t seen = 0;
+    uint32_t cnt[NC][kLevels];
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        cgp[p] = kLanesPerPass * p + lane;
-        act[p] = lane < kLanesPerPass && cgp[p] < G;
-        ccols[p] = act[p] ? codon_cols_of(cgp[p], W) : 0u;
-        actb[p] = uni64(__ballot(act[p]));
-        seen[p] = 0;
-        // columns of this word at or beyond W: a base there is outside the window (the reference writes past the row)
-        const int over = W - cgp[p] * 32;
-        tail[p] = (lane < kLanesPerPass || cgp[p] >= G) ? (over >= 32 ? 0u : over <= 0 ? 0xffffffffu : (0xffffffffu << over)) : 0u;
-        const int gw = min(cgp[p], G + 1);
-        gx[p] = gl[gw * 4];
-        gy[p] = gl[gw * 4 + 1];
-        gz[p] = gl[gw * 4 + 2];
+    for (int k = 0; k < NC; ++k)
 #pragma unroll
-        for (int k = 0; k < NC; ++k)
-#pragma unroll
-            for (int l = 0; l < kLevels; ++l) cnt[p][k][l] = 0;
-    }
+        for (int l = 0; l < kLevels; ++l) cnt[k][l] = 0;
 
-    // ---- batches are drawn from the workgroup's counter: the t-th draw is batch t * workgroups + this workgroup
+    // ---- batches are drawn from the role's counter of the workgroup: the t-th draw is batch t * workgroups + this workgroup
     const uint32_t n_batches = (uint32_t)a.n_batches;
     uint32_t n_taken = 0;
     auto draw = [&]() -> uint32_t {
         uint32_t t = 0xffffffffu;
         if (n_taken < (uint32_t)kMaxBatchesPerWave) {
-            if (lane == 0) t = __hip_atomic_fetch_add(draw_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) t = __hip_atomic_fetch_add(&draw_ctr[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             t = uni(t);
             n_taken = uni(n_taken + 1u);
         }
         const uint32_t b = t == 0xffffffffu ? 0xffffffffu : t * nwg + wg;
         return b < n_batches ? b : 0xffffffffu;
     };
-    const c_u64_ptr go = (c_u64_ptr)(uintptr_t)a.group_off;
-    const c_i32_ptr rsv = (c_i32_ptr)(uintptr_t)a.ref_start;
+    // the table entries of a batch's reads: two vector loads, lane i = read i (lane 8 = the end of read 7); clamped indices
+    // -- a read past the shard's end, and every read of "no batch", has no groups
+    const uint32_t* const go32 = reinterpret_cast<const uint32_t*>(a.group_off);
     const uint64_t bop_base = (uint64_t)(uintptr_t)a.bop;
-    // the eight reads of a batch: their table entries come through scalar loads (clamped indices) that are issued TWO
-    // batches ahead, all sixteen at once, so that nothing in the loop waits for them; a read past the shard's end has
-    // no groups
-    struct RawRows {
-        uint64_t o[kRows + 1];
-        int32_t rs[kRows];
-        uint32_t n_here;
-    };
-    auto fetch_raw = [&](uint32_t b, RawRows& raw) {
+    auto fetch_table = [&](uint32_t b, uint32_t& go_lo, uint32_t& go_hi, int32_t& rs) {
         const uint64_t r0 = a.read_lo + (uint64_t)(b == 0xffffffffu ? 0u : b) * kRows;
-        const uint64_t left = a.read_hi - r0;  // >= 1
-        const uint32_t n_here = b == 0xffffffffu ? 0u : (uint32_t)(left < (uint64_t)kRows ? left : (uint64_t)kRows);
-        raw.n_here = uni(n_here);
-        const uint32_t last = n_here ? n_here - 1u : 0u;
-#pragma unroll
-        for (int i = 0; i < kRows; ++i) {
-            const uint64_t r = r0 + (uint64_t)min((uint32_t)i, last);
-            raw.o[i] = go[r];
-            raw.rs[i] = rsv[r];
-        }
-        raw.o[kRows] = go[r0 + (uint64_t)last + 1u];
+        const uint64_t r = min(r0 + (uint64_t)min(lane, kRows), a.read_hi);
+        go_lo = go32[2 * r];
+        go_hi = go32[2 * r + 1];
+        rs = a.ref_start[min(r, a.read_hi - 1)];
     };
-    auto describe = [&](const RawRows& raw, RowDesc (&rd)[kRows]) {
-        uint32_t bad = 0;
-#pragma unroll
-        for (int i = 0; i < kRows; ++i) {
-            const uint64_t o0 = raw.o[i], o1 = (uint32_t)(i + 1) >= raw.n_here ? raw.o[kRows] : raw.o[i + 1];
-            const int32_t rel = ((raw.rs[i] - a.origin) >> 5) - a.word0;
-            const uint32_t ng = (uint32_t)i < raw.n_here ? (uint32_t)o1 - (uint32_t)o0 : 0u;
-            rd[i].base = uni64(bop_base + (o0 << 4));
-            rd[i].ng = uni(ng);
-            rd[i].rel = (int32_t)uni((uint32_t)rel);
-            // a read that reaches outside the window: assert(pos >= 0) / a write past the row (src/MSA.cpp:149)
-            bad |= (ng != 0u && (rel < 0 || rel + (int32_t)ng > G)) ? 1u : 0u;
-        }
-        if (bad) my_err |= DEVERR_WINDOW;
+    auto make_table = [&](uint32_t b, uint32_t go_lo, uint32_t go_hi, int32_t rs) -> RowTable {
+        const uint64_t o0 = ((uint64_t)go_hi << 32) | go_lo;
+        const uint32_t next_lo = dpp_next_lane(go_lo);
+        const uint64_t r0 = a.read_lo + (uint64_t)(b == 0xffffffffu ? 0u : b) * kRows;
+        const bool there = b != 0xffffffffu && r0 + (uint64_t)lane < a.read_hi && lane < kRows;
+        const uint32_t ng = there ? next_lo - go_lo : 0u;  // a read spans < 2^32 groups
+        const int32_t rel = ((rs - a.origin) >> 5) - a.word0;  // window word of the read's first group
+        const uint64_t base = bop_base + (o0 << 4);
+        // a read that reaches outside the window: assert(pos >= 0) / a write past the row (src/MSA.cpp:149)
+        if (ng != 0u && (rel < 0 || rel + (int32_t)ng > a.Gtot)) my_err |= DEVERR_WINDOW;
+        RowTable t;
+        t.w0 = (uint32_t)base;
+        t.w1 = (uint32_t)(base >> 32) & 0xffffu;
+        t.nb = ng << 4;
+        t.rel16 = rel << 4;
+        return t;
     };
-    // one word of one read: group (window word - rel) of the read, zeros outside it (the buffer's range check)
-    const int lane_word[2] = {lane, kLanesPerPass + lane};
-    auto load_word = [&](const RowDesc& rd, int p) -> uint4 {
-        const int k = lane_word[p] - rd.rel;
-        const auto v = __builtin_amdgcn_raw_buffer_load_b128(
-            __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)rd.base, 0, (int)(rd.ng << 4), 0x00020000), k << 4, 0, 0);
+    // one word of one read: group (window word - rel) of the read, zeros outside it (the buffer's range check); `ins` says
+    // whether this lane's word lies inside the read (a lane outside loaded zeros, which would read as 32 matching 'A's)
+    auto load_word = [&](const RowTable& t, int i, uint32_t& ins) -> uint4 {
+        const uint32_t nb = lane_value(t.nb, i);
+        const int32_t koff = lw16 - (int32_t)lane_value((uint32_t)t.rel16, i);
+        ins = (uint32_t)koff < nb ? 0xffffffffu : 0u;
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(uintptr_t)(((uint64_t)lane_value(t.w1, i) << 32) | lane_value(t.w0, i)), 0, (int)nb, 0x00020000);
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, koff, 0, 0);
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
 
@@ -205,23 +199,24 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
         for (uint32_t e = lane; e < nq; e += 64) {
             const uint4 lo = q4[e];  // V, X, B0, B1 of the word
             const uint32_t tag = qt[e];
-            const int cg = (int)(tag & 0xffu);
+            const int cgq = (int)(tag & 0xffu);       // word of the slab: guide words and LDS tables
+            const int cgw = a.slab_w0 + cgq;          // word of the window: columns of the matrices
             const uint32_t hv = (tag >> 8) & 3u, hb0 = (tag >> 10) & 3u, hb1 = (tag >> 12) & 3u;  // the next word's first two columns
-            const uint4 gl_lo = *reinterpret_cast<const uint4*>(gl + cg * 4), gl_hi = *reinterpret_cast<const uint4*>(gl + cg * 4 + 4);
-            const uint32_t cc = codon_cols_of(cg, W);
+            const uint4 gl_lo = *reinterpret_cast<const uint4*>(gl + cgq * 4), gl_hi = *reinterpret_cast<const uint4*>(gl + cgq * 4 + 4);
+            const uint32_t cc = codon_cols_of(cgw, W);
             const uint32_t m_lo = lo.x & gl_lo.x & ~((lo.z ^ gl_lo.y) | (lo.w ^ gl_lo.z));
             const uint32_t m_hi = hv & gl_hi.x & ~((hb0 ^ gl_hi.y) | (hb1 ^ gl_hi.z));
             const uint32_t cm = m_lo & funnel(m_lo, m_hi, 1) & funnel(m_lo, m_hi, 2) & cc;
             const uint32_t cv = lo.x & funnel(lo.x, hv, 1) & funnel(lo.x, hv, 2) & cc;
-            const int cbase = cg * 32;
+            const int cbase = cgw * 32, lbase = cgq * 32;
             // columns of this word inside the window: a read that reaches past column W is reported (tail, DEVERR_WINDOW)
             // and must not count beyond the caller's matrices
-            const int over = W - cbase;
-            const uint32_t inw = over >= 32 ? 0xffffffffu : over <= 0 ? 0u : ((1u << over) - 1u);
+            const int ov = W - cbase;
+            const uint32_t inw = ov >= 32 ? 0xffffffffu : ov <= 0 ? 0u : ((1u << ov) - 1u);
             const uint32_t nd = lo.x & ~m_lo & inw, cd = cv & ~cm, nn = COUNT_N ? 0u : (lo.y & lo.z & inw);
             // what matches the set's alt haplotype -- a minor variant carried by a share of the reads -- is counted in
             // LDS (the sum leaves with the workgroup's partial); only what matches neither pays a global atomic
-            const uint4 al = *reinterpret_cast<const uint4*>(gl2 + cg * 4), ah = *reinterpret_cast<const uint4*>(gl2 + cg * 4 + 4);
+            const uint4 al = *reinterpret_cast<const uint4*>(gl2 + cgq * 4), ah = *reinterpret_cast<const uint4*>(gl2 + cgq * 4 + 4);
             const uint32_t am_lo = lo.x & al.x & ~((lo.z ^ al.y) | (lo.w ^ al.z));
             const uint32_t am_hi = hv & ah.x & ~((hb0 ^ ah.y) | (hb1 ^ ah.z));
             const uint32_t nd_alt = nd & am_lo;
@@ -230,17 +225,39 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
-                __hip_atomic_fetch_add(&altc[cbase + j], ((nd_alt >> j) & 1u) | (((cd_alt >> j) & 1u) << 16), __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add(&altc[lbase + j], ((nd_alt >> j) & 1u) | (((cd_alt >> j) & 1u) << 16), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            bits = (nd & ~nd_alt) | nn;  // disjoint: nd lies in V, nn in X
+            // An ISOLATED substitution -- a base that differs from the guide's while the two columns on either side of
+            // it, all inside this word, match the guide (what a sequencing error looks like) -- changes exactly one
+            // nucleotide bin and the three codons that hold it, each in one position: it is counted ONCE, in LDS, by its
+            // column and the rank of the base read, and the fold turns the sums into the four bins.  Returnless global
+            // atomics run at ~26e9 / s on the whole chip; at the reference's error rate (0.05 %) the four atomics per
+            // substitution were a third of the kernel's time, and uniform noise of 2 % cost 20 x a clean sample.
+            uint32_t nd_rest = nd & ~nd_alt, cd_rest = cd & ~cd_alt;
+            bits = nd_rest & 0x3ffffffcu;  // columns 2 .. 29 of the word: all five columns and three codon starts inside it
+            while (bits) {
+                const int j = __ffs(bits) - 1;
+                bits &= bits - 1;
+                if (((m_lo >> (j - 2)) & 0x1bu) != 0x1bu) continue;  // a neighbour deviates, is a gap or is not there
+                const uint32_t code = ((lo.z >> j) & 1u) | (((lo.w >> j) & 1u) << 1);
+                const uint32_t g = ((gl_lo.y >> j) & 1u) | (((gl_lo.z >> j) & 1u) << 1);
+                const uint32_t r = (code - g - 1u) & 3u;  // 0 .. 2: code != g
+                if (r < 2u)
+                    __hip_atomic_fetch_add(&subA[lbase + j], 1u << (16u * r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    __hip_atomic_fetch_add(&subB[lbase + j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                nd_rest &= ~(1u << j);
+                cd_rest &= ~(7u << (j - 2));  // the codons that start at j - 2, j - 1, j: the fold adds them where they count
+            }
+            bits = nd_rest | nn;  // disjoint: nd lies in V, nn in X
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
                 const uint32_t code = ((nn >> j) & 1u) ? 5u : (((lo.z >> j) & 1u) | (((lo.w >> j) & 1u) << 1));
                 atomicAdd(&a.nuc[(uint32_t)(cbase + j) * 6u + code], 1u);  // MSAColumn::IncCounts, MSA.inl:66
             }
-            bits = cd & ~cd_alt;
+            bits = cd_rest;
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
@@ -256,89 +273,55 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
         wave_sync();
     };
 
-    // ---- four reads of one pass: the loaded words against the guide (MSAByColumn's loop, src/MSA.cpp:68-87; CodonsAt,
-    // :126-136,197-219); match / gap / codon / N masks into levels 0-1 of the counters (returns the weight-4 carries),
-    // words with anything else on the queue
-    auto rows4 = [&](const int p, const uint4 (&wd)[4], const RowDesc* rd, uint32_t (&carry)[NC]) {
-        uint32_t even[NC], twos[NC];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 w = wd[i];  // nucleotide bit 0, bit 1, op bit 0, bit 1
-            // a lane outside the read loaded zeros, which would read as 32 matching 'A's: only lanes inside count
-            const uint32_t inside = (uint32_t)(lane_word[p] - rd[i].rel) < rd[i].ng ? 0xffffffffu : 0u;
-            const uint32_t V = ~(w.z | w.w) & inside;                                 // op 0: '=' / 'X'
-            const uint32_t X = w.z & ~w.w;                                            // op 1: '-' or literal N
-            const uint32_t f = (w.x ^ gy[p]) | (w.y ^ gz[p]);
-            const uint32_t m = V & gx[p] & ~f;                                        // the guide's base
-            const uint32_t m_hi = dpp_next_lane(m), v_hi = dpp_next_lane(V);
-            // codon at column c = columns c, c + 1, c + 2.  Columns that cannot start a codon (the window's first and its
-            // last two, codon_cols_of) are NOT masked here: their counters are cleared at the flush, and the drain masks
-            // them where it counts a deviation -- two operations less per word for the two words they can be in
-            const uint32_t cm = m & funnel(m, m_hi, 1) & funnel(m, m_hi, 2);
-            const uint32_t cv = V & funnel(V, v_hi, 1) & funnel(V, v_hi, 2);
-            const uint32_t nn = X & w.x;
-            seen[p] |= V | X;
-            uint32_t x[NC];
-            x[0] = m;
-            x[1] = X & ~w.x;
-            x[2] = cm;
-            if (COUNT_N) x[NC - 1] = nn;
-            const uint32_t dev = (V & ~m) | (cv & ~cm) | (COUNT_N ? 0u : nn);
-            const uint64_t bal = __ballot(dev != 0) & actb[p];  // lanes that count (not the lending lane, not lanes past the window)
-            if (bal) {  // wave-uniform, rare
-                const bool has = (bal >> lane) & 1u;
-                // the next word's first two columns (codons reach into them), for every lane: all lanes are active here
-                const uint32_t b0 = w.x & (V | X), b1 = w.y & V;
-                const uint32_t tag = (uint32_t)cgp[p] | ((v_hi & 3u) << 8) | ((dpp_next_lane(b0) & 3u) << 10) | ((dpp_next_lane(b1) & 3u) << 12);
-                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, qn));
-                if (has) {
-                    q4[pos] = make_uint4(V, X, b0, b1);
-                    qt[pos] = tag;
-                }
-                qn = uni(qn + (uint32_t)__popcll(bal));
+    // ---- one read: the loaded word against the guide (MSAByColumn's loop, src/MSA.cpp:68-87; CodonsAt, :126-136,197-219)
+    // -> its match / gap / codon / N masks; a word with anything else goes on the queue
+    auto one_row = [&](const uint4 w, const uint32_t ins, uint32_t (&x)[NC]) {
+        const uint32_t V = ~(w.z | w.w) & ins;   // op 0: '=' / 'X'   (w = nucleotide bit 0, bit 1, op bit 0, bit 1)
+        const uint32_t X = w.z & ~w.w;           // op 1: '-' or literal N
+        const uint32_t f = (w.x ^ gy) | (w.y ^ gz);
+        const uint32_t m = V & gx & ~f;          // the guide's base
+        const uint32_t m_hi = dpp_next_lane(m), v_hi = dpp_next_lane(V);
+        // codon at column c = columns c, c + 1, c + 2.  Columns that cannot start a codon (the window's first and its
+        // last two, codon_cols_of) are NOT masked here: their counters are cleared at the flush, and the drain masks
+        // them where it counts a deviation -- two operations less per word for the two words they can be in
+        const uint32_t cm = m & funnel(m, m_hi, 1) & funnel(m, m_hi, 2);
+        const uint32_t cv = V & funnel(V, v_hi, 1) & funnel(V, v_hi, 2);
+        const uint32_t nn = X & w.x;
+        seen |= V | X;
+        x[0] = m;
+        x[1] = X & ~w.x;
+        x[2] = cm;
+        if (COUNT_N) x[NC - 1] = nn;
+        const uint32_t dev = (V & ~m) | (cv & ~cm) | (COUNT_N ? 0u : nn);
+        const uint64_t bal = __ballot(dev != 0) & actb;  // lanes that count (not the lending lane, not lanes past the window)
+        if (bal) {  // wave-uniform
+            const bool has = (bal >> lane) & 1u;
+            // the next word's first two columns (codons reach into them), for every lane: all lanes are active here
+            const uint32_t b0 = w.x & (V | X), b1 = w.y & V;
+            const uint32_t tag = (uint32_t)lw | ((v_hi & 3u) << 8) | ((dpp_next_lane(b0) & 3u) << 10) | ((dpp_next_lane(b1) & 3u) << 12);
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, qn));
+            if (has) {
+                q4[pos] = make_uint4(V, X, b0, b1);
+                qt[pos] = tag;
             }
-#pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                if (i == 0 || i == 2) {
-                    even[k] = x[k];
-                } else if (i == 1) {
-                    csa(cnt[p][k][0], even[k], x[k], cnt[p][k][0], twos[k]);
-                } else {
-                    uint32_t t2;
-                    csa(cnt[p][k][0], even[k], x[k], cnt[p][k][0], t2);
-                    csa(cnt[p][k][1], twos[k], t2, cnt[p][k][1], carry[k]);
-                }
-            }
-        }
-    };
-    auto ripple_all = [&](const int p, uint32_t (&carry)[NC]) {  // carries into level 3 of every counter of pass p
-        uint32_t any = 0;
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            carry[k] = ripple<3, kLowLevels>(cnt[p][k], carry[k]);
-            any |= carry[k];
-        }
-        if (__ballot(any != 0)) {
-#pragma unroll
-            for (int k = 0; k < NC; ++k) (void)ripple<kLowLevels, kLevels>(cnt[p][k], carry[k]);
+            qn = uni(qn + (uint32_t)__popcll(bal));
         }
     };
 
     // ---- the stream: the words of the current batch sit in registers; the registers of four reads are re-loaded
-    // with the next batch's words as soon as those four reads are counted
-    RowDesc cur[kRows], nxt[kRows];
-    RawRows raw;
-    uint4 wd[PASSES][kRows];
+    // with the next batch's words as soon as those four reads are counted; the table of the batch after next is in flight
     uint32_t b_cur = draw(), b_nxt = draw(), b_nn = draw();
-    fetch_raw(b_cur, raw);
-    describe(raw, cur);
-    fetch_raw(b_nxt, raw);
-    describe(raw, nxt);
-    fetch_raw(b_nn, raw);  // in flight across the first batch
+    uint32_t f_lo, f_hi;
+    int32_t f_rs;
+    fetch_table(b_cur, f_lo, f_hi, f_rs);
+    RowTable tab = make_table(b_cur, f_lo, f_hi, f_rs);
+    uint4 wd[kRows];
+    uint32_t ins[kRows];
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p)
-#pragma unroll
-        for (int i = 0; i < kRows; ++i) wd[p][i] = load_word(cur[i], p);
+    for (int i = 0; i < kRows; ++i) wd[i] = load_word(tab, i, ins[i]);
+    fetch_table(b_nxt, f_lo, f_hi, f_rs);
+    tab = make_table(b_nxt, f_lo, f_hi, f_rs);
+    fetch_table(b_nn, f_lo, f_hi, f_rs);
     if (with_bounds) {  // wave maxima (order-preserving unsigned codes) meet in LDS, one atomic pair per workgroup goes out
         uint32_t k_lo = ~((uint32_t)b_lo ^ 0x80000000u), k_hi = (uint32_t)b_hi ^ 0x80000000u;
         for (int d = 32; d >= 1; d >>= 1) {
@@ -346,55 +329,67 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
             k_hi = max(k_hi, (uint32_t)__shfl_xor((int)k_hi, d));
         }
         if (lane == 0) {
-            atomicMax(&draw_ctr[1], k_lo);
-            atomicMax(&draw_ctr[2], k_hi);
+            atomicMax(&draw_ctr[2], k_lo);
+            atomicMax(&draw_ctr[3], k_hi);
         }
     }
     while (b_cur != 0xffffffffu) {
+        uint32_t c4[2][NC], c8[NC];
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            uint32_t c4a[NC], c4b[NC], c8[NC];
-            {
-                const uint4 w4[4] = {wd[p][0], wd[p][1], wd[p][2], wd[p][3]};
-                rows4(p, w4, cur, c4a);
+        for (int h = 0; h < 2; ++h) {
+            uint32_t even[NC], twos[NC];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wd[p][i] = load_word(nxt[i], p);
+            for (int i = 0; i < 4; ++i) {
+                uint32_t x[NC];
+                one_row(wd[4 * h + i], ins[4 * h + i], x);
+#pragma unroll
+                for (int k = 0; k < NC; ++k) {  // streaming Harley-Seal: rows fold in pairs as they come
+                    if (i == 0 || i == 2) {
+                        even[k] = x[k];
+                    } else if (i == 1) {
+                        csa(cnt[k][0], even[k], x[k], cnt[k][0], twos[k]);
+                    } else {
+                        uint32_t t2;
+                        csa(cnt[k][0], even[k], x[k], cnt[k][0], t2);
+                        csa(cnt[k][1], twos[k], t2, cnt[k][1], c4[h][k]);
+                    }
+                }
+                if ((i & 1) && qn > (uint32_t)(kQueueCap - kQueueRoom)) drain();
             }
-            if (qn > (uint32_t)(kQueueCap - 256)) drain();  // four reads add at most 256 entries
-            {
-                const uint4 w4[4] = {wd[p][4], wd[p][5], wd[p][6], wd[p][7]};
-                rows4(p, w4, cur + 4, c4b);
 #pragma unroll
-                for (int i = 4; i < 8; ++i) wd[p][i] = load_word(nxt[i], p);
+            for (int i = 0; i < 4; ++i) wd[4 * h + i] = load_word(tab, 4 * h + i, ins[4 * h + i]);
+        }
+        {
+            uint32_t any = 0;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                csa(cnt[k][2], c4[0][k], c4[1][k], cnt[k][2], c8[k]);
+                c8[k] = ripple<3, kLowLevels>(cnt[k], c8[k]);
+                any |= c8[k];
             }
+            if (__ballot(any != 0)) {
 #pragma unroll
-            for (int k = 0; k < NC; ++k) csa(cnt[p][k][2], c4a[k], c4b[k], cnt[p][k][2], c8[k]);
-            ripple_all(p, c8);
-            if (qn > (uint32_t)(kQueueCap - 256)) drain();
+                for (int k = 0; k < NC; ++k) (void)ripple<kLowLevels, kLevels>(cnt[k], c8[k]);
+            }
         }
         if (qn >= (uint32_t)kQueueDrainAt) drain();
-#pragma unroll
-        for (int i = 0; i < kRows; ++i) cur[i] = nxt[i];
-        describe(raw, nxt);  // the entries fetched a batch ago
+        tab = make_table(b_nn, f_lo, f_hi, f_rs);  // the entries fetched a batch ago
         b_cur = b_nxt;
         b_nxt = b_nn;
         b_nn = draw();
-        fetch_raw(b_nn, raw);
+        fetch_table(b_nn, f_lo, f_hi, f_rs);
     }
     if (qn) drain();
 
     // ---- flush: per column the guide's and the alt haplotype's bins (meta), the alt counts; then the waves' bit-sliced
-    // counters added up while still bit-sliced, one wave per (counter, pass), the sum transposed and stored
+    // counters added up while still bit-sliced, one wave per (counter, role), the sum transposed and stored
+    if (seen & tail) my_err |= DEVERR_WINDOW;  // a base at or beyond column W
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        if (seen[p] & tail[p]) my_err |= DEVERR_WINDOW;  // a base at or beyond column W
-#pragma unroll
-        for (int l = 0; l < kLevels; ++l) cnt[p][2][l] &= ccols[p];  // columns that cannot start a codon were counted along
-    }
+    for (int l = 0; l < kLevels; ++l) cnt[2][l] &= ccols;  // columns that cannot start a codon were counted along
     __syncthreads();
     if (with_bounds && tid == 0) {  // the last workgroup in publishes the bounds and clears the accumulators
-        atomicMax(&a.bounds_acc[0], draw_ctr[1]);
-        atomicMax(&a.bounds_acc[1], draw_ctr[2]);
+        atomicMax(&a.bounds_acc[0], draw_ctr[2]);
+        atomicMax(&a.bounds_acc[1], draw_ctr[3]);
         __threadfence();
         if (atomicAdd(&a.bounds_acc[2], 1u) == gridDim.x - 1) {
             __threadfence();
@@ -406,7 +401,7 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
         }
     }
     const int cols = G * 32;
-    uint32_t* const part = a.partials + (size_t)wg * (NC + 4) * cols;
+    uint32_t* const part = a.partials + (size_t)wg * (NC + 6) * cols;
     auto meta_of = [&](const uint32_t* g, int c) -> uint32_t {
         auto bit = [&](int plane, int cc) -> uint32_t { return (g[(cc >> 5) * 4 + plane] >> (cc & 31)) & 1u; };
         const uint32_t v0 = bit(0, c), v1 = bit(0, c + 1), v2 = bit(0, c + 2);
@@ -419,70 +414,63 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
         part[(size_t)(NC + 1) * cols + c] = ac & 0xffffu;
         part[(size_t)(NC + 2) * cols + c] = ac >> 16;
         part[(size_t)(NC + 3) * cols + c] = meta_of(gl2, c);
+        part[(size_t)(NC + 4) * cols + c] = subA[c];
+        part[(size_t)(NC + 5) * cols + c] = subB[c];
     }
     constexpr int SL = kLevels + 4;  // levels of a sum over <= 16 waves
-    uint32_t* const slab = lds;      // [passes of the round][NC][NWV][kLevels][64]: queues and guide are dead
-    auto round = [&](const int p_lo, const int p_hi) {
+    uint32_t* const slab = lds;      // [roles of the round][NC][waves of a role][kLevels][64]: queues and guide are dead
+    auto round = [&](const int r_lo, const int r_hi) {
         __syncthreads();  // the guide words / the previous round's sums have been read
+        if (role >= r_lo && role < r_hi) {
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-            if (p >= p_lo && p < p_hi) {
+            for (int k = 0; k < NC; ++k)
 #pragma unroll
-                for (int k = 0; k < NC; ++k)
-#pragma unroll
-                    for (int l = 0; l < kLevels; ++l) slab[((((p - p_lo) * NC + k) * NWV + wave) * kLevels + l) * 64 + lane] = cnt[p][k][l];
-            }
+                for (int l = 0; l < kLevels; ++l) slab[((((role - r_lo) * NC + k) * waves_per_role + wave_in_role) * kLevels + l) * 64 + lane] = cnt[k][l];
+        }
         __syncthreads();
-        for (int job = wave; job < NC * (p_hi - p_lo); job += NWV) {  // wave-uniform
-            const int k = job % NC, pj = p_lo + job / NC;
+        for (int job = wave; job < NC * (r_hi - r_lo); job += NWV) {  // wave-uniform
+            const int k = job % NC, rj = r_lo + job / NC;
+            const uint32_t* const base = slab + (size_t)((rj - r_lo) * NC + k) * waves_per_role * kLevels * 64;
+            uint32_t sum[SL];
 #pragma unroll
-            for (int p = 0; p < PASSES; ++p) {
-                if (p != pj) continue;
-                const uint32_t* const base = slab + (size_t)((p - p_lo) * NC + k) * NWV * kLevels * 64;
-                uint32_t sum[SL];
+            for (int l = 0; l < SL; ++l) sum[l] = 0;
+            for (int e = 0; e < waves_per_role; ++e) {
+                const uint32_t* src = base + e * kLevels * 64 + lane;
+                uint32_t carry = 0;
 #pragma unroll
-                for (int l = 0; l < SL; ++l) sum[l] = 0;
-                for (int e = 0; e < NWV; ++e) {
-                    const uint32_t* src = base + e * kLevels * 64 + lane;
-                    uint32_t carry = 0;
+                for (int l = 0; l < SL; ++l) csa(sum[l], l < kLevels ? src[l * 64] : 0u, carry, sum[l], carry);
+            }
+            const int cgj = kLanesPerPass * rj + lane;  // this lane's word in role rj
+            if (lane < kLanesPerPass && cgj < G) {
+                static_assert(SL <= 16, "the transposition holds 16 levels");
+                uint32_t t16[16];
 #pragma unroll
-                    for (int l = 0; l < SL; ++l) csa(sum[l], l < kLevels ? src[l * 64] : 0u, carry, sum[l], carry);
-                }
-                if (act[p]) {
-                    static_assert(SL <= 16, "the transposition holds 16 levels");
-                    uint32_t t16[16];
+                for (int l = 0; l < 16; ++l) t16[l] = l < SL ? sum[l] : 0u;
+                transpose16x2(t16);
+                uint4* dst = reinterpret_cast<uint4*>(part + (size_t)k * cols + cgj * 32);
 #pragma unroll
-                    for (int l = 0; l < 16; ++l) t16[l] = l < SL ? sum[l] : 0u;
-                    transpose16x2(t16);
-                    uint4* dst = reinterpret_cast<uint4*>(part + (size_t)k * cols + cgp[p] * 32);
-#pragma unroll
-                    for (int r = 0; r < 16; r += 4) {
-                        dst[r >> 2] = make_uint4(t16[r] & 0xffffu, t16[r + 1] & 0xffffu, t16[r + 2] & 0xffffu, t16[r + 3] & 0xffffu);
-                        dst[4 + (r >> 2)] = make_uint4(t16[r] >> 16, t16[r + 1] >> 16, t16[r + 2] >> 16, t16[r + 3] >> 16);
-                    }
+                for (int r = 0; r < 16; r += 4) {
+                    dst[r >> 2] = make_uint4(t16[r] & 0xffffu, t16[r + 1] & 0xffffu, t16[r + 2] & 0xffffu, t16[r + 3] & 0xffffu);
+                    dst[4 + (r >> 2)] = make_uint4(t16[r] >> 16, t16[r + 1] >> 16, t16[r + 2] >> 16, t16[r + 3] >> 16);
                 }
             }
         }
     };
     if (a.flush_wide) {
-        round(0, PASSES);
+        round(0, n_roles);
     } else {
-        for (int p = 0; p < PASSES; ++p) round(p, p + 1);
+        for (int r = 0; r < n_roles; ++r) round(r, r + 1);
     }
     if (my_err) atomicOr(a.err, my_err);
 }
 
 typedef void (*rows_kernel_fn)(RowsArgs);
-rows_kernel_fn pick_rows_kernel(int passes, bool many_n)
-{
-    if (many_n) return passes == 1 ? pileup_rows_kernel<1, true> : pileup_rows_kernel<2, true>;
-    return passes == 1 ? pileup_rows_kernel<1, false> : pileup_rows_kernel<2, false>;
-}
+rows_kernel_fn pick_rows_kernel(bool many_n) { return many_n ? pileup_rows_kernel<true> : pileup_rows_kernel<false>; }
 
 }  // namespace
 
 // The pileup of an aligned set inside [win_begin0, win_begin0 + W).  *handled = false: not this kernel's case (no guide,
-// a window off the set's word grid or wider than 126 words, exotic symbols, QV planes a threshold would read) -- the
+// a window off the set's word grid, exotic symbols, QV planes a threshold would read) -- the
 // caller takes the read-space kernels, for which an aligned set is a plain-layout set like any other.
 // fixed_partials / fixed_bytes: msq_pileup_noalloc's built-in buffer for the workgroup partials (nothing is allocated).
 // d_step_bounds / d_dev: msq_pileup_step -- the shard's bounds out of the same launch, deviations into the context's
@@ -499,14 +487,14 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
         if (thrs[k] >= 0 && planes[k]) return MSQ_OK;
     const int64_t off = (int64_t)win_begin0 - R.align_origin;
     if (off % 32 != 0) return MSQ_OK;
-    const int G = (W + 31) / 32;
-    if (G > 2 * kLanesPerPass) return MSQ_OK;
-    if (d_step_bounds && !R.ref_end) return MSQ_OK;
-    const int passes = G <= kLanesPerPass ? 1 : 2;
+    const int Gtot = (W + 31) / 32;
+    // windows of more than 126 words go slab by slab: a launch loads, of every read, only the words of its slab (and the
+    // one word behind it that the last codons reach into) -- no read is streamed twice, no partition is needed
+    const int n_slabs = (Gtot + 2 * kLanesPerPass - 1) / (2 * kLanesPerPass);
+    const int Gslab = (Gtot + n_slabs - 1) / n_slabs;
+    if (d_step_bounds && (n_slabs != 1 || !R.ref_end)) return MSQ_OK;  // the fused step is one launch
     const bool many_n = (R.flags & MSQ_READS_QV_BAKED) != 0;
     const int NC = many_n ? 4 : 3;
-    const uint64_t reads_per_launch = (uint64_t)ctx->n_cu * kRowsWaves * kMaxBatchesPerWave * kRows;
-    if (d_step_bounds && R.n_reads > reads_per_launch) return MSQ_OK;  // the fused step is one launch
 
     RowsArgs a;
     memset(&a, 0, sizeof(a));
@@ -520,7 +508,7 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
     a.W = W;
     a.origin = R.align_origin;
     a.word0 = (int32_t)(off / 32);
-    a.G = G;
+    a.Gtot = Gtot;
     a.nuc = d_dev ? d_dev : d_nuc;
     a.codon = d_dev ? d_dev + (size_t)W * 6 : d_codon;
     a.err = ctx->d_err;
@@ -528,53 +516,64 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
         a.bounds_acc = ctx->d_small + 16;
         a.bounds_out = d_step_bounds;
     }
-    rows_kernel_fn kern = pick_rows_kernel(passes, many_n);
+    rows_kernel_fn kern = pick_rows_kernel(many_n);
     bool marked = false;
-    for (uint64_t lo = 0; lo < R.n_reads; lo += reads_per_launch) {
-        const uint64_t hi = std::min<uint64_t>(R.n_reads, lo + reads_per_launch);
-        const uint64_t n_batches = (hi - lo + kRows - 1) / kRows;
-        int w = kRowsWaves, n_wg = ctx->n_cu;
-        if ((uint64_t)n_wg * w > n_batches) {  // small inputs: fewer, thinner workgroups
-            w = (int)std::max<uint64_t>(1, std::min<uint64_t>(w, (n_batches + ctx->n_cu - 1) / ctx->n_cu));
-            n_wg = (int)((n_batches + w - 1) / w);
+    for (int slab = 0; slab < n_slabs; ++slab) {
+        const int G = std::min(Gslab, Gtot - slab * Gslab);
+        const int n_roles = G <= kLanesPerPass ? 1 : 2;
+        a.G = G;
+        a.slab_w0 = slab * Gslab;
+        a.n_roles = n_roles;
+        // every role sees every batch: a workgroup counts (waves of a role) x 127 batches
+        const uint64_t reads_per_launch = (uint64_t)ctx->n_cu * (kRowsWaves / n_roles) * kMaxBatchesPerWave * kRows;
+        if (d_step_bounds && R.n_reads > reads_per_launch) return MSQ_OK;
+        for (uint64_t lo = 0; lo < R.n_reads; lo += reads_per_launch) {
+            const uint64_t hi = std::min<uint64_t>(R.n_reads, lo + reads_per_launch);
+            const uint64_t n_batches = (hi - lo + kRows - 1) / kRows;
+            int wr = kRowsWaves / n_roles, n_wg = ctx->n_cu;  // waves per role
+            if ((uint64_t)n_wg * wr > n_batches) {  // small inputs: fewer, thinner workgroups
+                wr = (int)std::max<uint64_t>(1, std::min<uint64_t>(wr, (n_batches + ctx->n_cu - 1) / ctx->n_cu));
+                n_wg = (int)((n_batches + wr - 1) / wr);
+            }
+            const int w = wr * n_roles;
+            const size_t stream_lds = (size_t)w * kQueueCap * 20 + 16 + (size_t)(G + 2) * 32 + (size_t)G * 128 * 3;
+            const size_t slab_lds = (size_t)NC * wr * kLevels * 256;  // one role's levels in the flush
+            const bool flush_wide = slab_lds * n_roles <= 160 * 1024 - 512;
+            const size_t lds = std::max(stream_lds, flush_wide ? slab_lds * n_roles : slab_lds);
+            if (lds > 160 * 1024 - 512) return marked ? msq_fail(MSQ_ERR_ARG, "msq_pileup: no LDS for a %d-word slab", G) : MSQ_OK;
+            a.flush_wide = flush_wide ? 1u : 0u;
+            const size_t need = (size_t)n_wg * (NC + 6) * G * 32 * 4;
+            void* s = fixed_partials;
+            if (fixed_partials) {
+                if (need > fixed_bytes)
+                    return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: %zu bytes of workgroup partials exceed the built-in %zu", need, fixed_bytes);
+            } else {
+                int rc = msq_scratch(ctx, need, &s);
+                if (rc != MSQ_OK) return rc;
+            }
+            a.partials = static_cast<uint32_t*>(s);
+            a.read_lo = lo;
+            a.read_hi = hi;
+            a.n_batches = n_batches;
+            if (!marked) {
+                msq_timing_mark_begin(ctx);
+                marked = true;
+            }
+            static size_t lds_set[2] = {0, 0};  // per kernel the largest dynamic LDS size set so far
+            const int ki = many_n ? 1 : 0;
+            if (lds > 48 * 1024 && lds > lds_set[ki]) {
+                MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                lds_set[ki] = lds;
+            }
+            hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
+            if (slab + 1 == n_slabs && hi == R.n_reads) msq_timing_mark_end(ctx);
+            MSQ_HIP(hipGetLastError());
+            const int col_blocks = (G * 32 + kFoldCols - 1) / kFoldCols;
+            const int slices = d_dev ? 1 : std::max(1, std::min(n_wg / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
+            hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
+                               a.slab_w0 * 32, W, d_nuc, d_codon, d_dev ? a.nuc : (uint32_t*)nullptr, d_dev ? a.codon : (uint32_t*)nullptr, NC + 6);
+            MSQ_HIP(hipGetLastError());
         }
-        const size_t stream_lds = (size_t)w * kQueueCap * 20 + 16 + (size_t)(G + 2) * 32 + (size_t)G * 128;
-        const size_t slab_lds = (size_t)NC * w * kLevels * 256;  // one pass's levels in the flush
-        const bool flush_wide = slab_lds * passes <= 160 * 1024 - 512;
-        const size_t lds = std::max(stream_lds, flush_wide ? slab_lds * passes : slab_lds);
-        if (lds > 160 * 1024 - 512) return MSQ_OK;
-        a.flush_wide = flush_wide ? 1u : 0u;
-        const size_t need = (size_t)n_wg * (NC + 4) * G * 32 * 4;
-        void* s = fixed_partials;
-        if (fixed_partials) {
-            if (need > fixed_bytes)
-                return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: %zu bytes of workgroup partials exceed the built-in %zu", need, fixed_bytes);
-        } else {
-            int rc = msq_scratch(ctx, need, &s);
-            if (rc != MSQ_OK) return rc;
-        }
-        a.partials = static_cast<uint32_t*>(s);
-        a.read_lo = lo;
-        a.read_hi = hi;
-        a.n_batches = n_batches;
-        if (!marked) {
-            msq_timing_mark_begin(ctx);
-            marked = true;
-        }
-        static size_t lds_set[4] = {0, 0, 0, 0};  // per kernel the largest dynamic LDS size set so far
-        const int ki = (passes - 1) * 2 + (many_n ? 1 : 0);
-        if (lds > 48 * 1024 && lds > lds_set[ki]) {
-            MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            lds_set[ki] = lds;
-        }
-        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
-        if (hi == R.n_reads) msq_timing_mark_end(ctx);
-        MSQ_HIP(hipGetLastError());
-        const int col_blocks = (G * 32 + kFoldCols - 1) / kFoldCols;
-        const int slices = d_dev ? 1 : std::max(1, std::min(n_wg / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, a.partials, n_wg, NC, G * 32, 0,
-                           W, d_nuc, d_codon, d_dev ? a.nuc : (uint32_t*)nullptr, d_dev ? a.codon : (uint32_t*)nullptr);
-        MSQ_HIP(hipGetLastError());
     }
     *handled = true;
     return MSQ_OK;

@@ -132,14 +132,19 @@ __device__ __forceinline__ uint32_t codon_cols_of(int cg, int W)  // cg: word of
 // trip for 256 workgroups), the 32 lanes of a column meet in LDS, and what is not zero there leaves as one global
 // atomic per bin.  blockIdx.y slices the workgroups further (more blocks, but as many more global atomics).
 constexpr int kFoldCols = 32, kFoldSubs = 32, kFoldTrip = 8;
+// rows: partial rows per workgroup -- NC + 4, or NC + 6 when the kernel also hands over its tables of isolated
+// substitutions (msq_pileup_rows.hip; every workgroup of such a launch counts against the same guide).
 __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols, int col0, int W,
                                               uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
-                                              uint32_t* __restrict__ dev_codon)
+                                              uint32_t* __restrict__ dev_codon, int rows)
 {
     constexpr int kCodStride = 65, kNucStride = 7;  // odd strides: the lanes of a wave are columns
     __shared__ uint32_t cod_acc[kFoldCols * kCodStride];
     __shared__ uint32_t nuc_acc[kFoldCols * kNucStride];
+    __shared__ uint32_t sub_acc[(kFoldCols + 2) * 3];  // isolated substitutions of the block's columns and the next two, by rank
+    const bool with_subs = rows > NC + 4;
     const int T = kFoldCols * kFoldSubs, tid = threadIdx.x;
+    for (int i = tid; i < (kFoldCols + 2) * 3; i += T) sub_acc[i] = 0;
     for (int i = tid; i < kFoldCols * kCodStride; i += T) cod_acc[i] = 0;
     for (int i = tid; i < kFoldCols * kNucStride; i += T) nuc_acc[i] = 0;
     const int cl = tid & (kFoldCols - 1), sub = tid / kFoldCols;
@@ -147,6 +152,7 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
     const int per = (n_wg + gridDim.y - 1) / gridDim.y;
     const int wg_lo = blockIdx.y * per, wg_hi = min(n_wg, wg_lo + per);
     const bool valid = c < cols && col0 + c < W;
+    uint32_t meta_first = 0;  // the guide's bins of this column as the first workgroup wrote them
     __syncthreads();
     if (valid) {
         uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0;
@@ -154,6 +160,10 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
         // guide's codon, set 1 = the alt haplotype's)
         uint32_t cod_sum[2] = {0, 0};
         int cod_idx[2] = {-1, -1};
+        // isolated substitutions (rows NC + 4, NC + 5) of this column, unpacked and summed.  A block is one 32-column
+        // word and an isolated substitution sits in columns 2 .. 29 of its word, so the codons it changes (they start
+        // up to two columns before it) all start in the same block: sub_acc's two margin entries stay zero
+        uint32_t sr[3] = {0, 0, 0};
         auto add_codon = [&](int set, uint32_t meta, uint32_t n) {
             if (!n) return;
             const int idx = (int)((meta >> 8) & 63u);
@@ -166,10 +176,13 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
         };
         for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += kFoldSubs * kFoldTrip) {
             uint32_t meta[kFoldTrip], m[kFoldTrip], g[kFoldTrip], cm[kFoldTrip], n4[kFoldTrip], am[kFoldTrip], acm[kFoldTrip], meta2[kFoldTrip];
+            uint32_t sa[kFoldTrip], sb[kFoldTrip];  // substitution tables of this column
 #pragma unroll
             for (int u = 0; u < kFoldTrip; ++u) {
                 const int wg = min(wg0 + kFoldSubs * u, wg_hi - 1);  // clamped: a slot past the end is loaded and ignored
-                const uint32_t* p = partials + (size_t)wg * (NC + 4) * cols;
+                const uint32_t* p = partials + (size_t)wg * rows * cols;
+                sa[u] = with_subs ? p[(size_t)(NC + 4) * cols + c] : 0u;
+                sb[u] = with_subs ? p[(size_t)(NC + 5) * cols + c] : 0u;
                 meta[u] = p[(size_t)NC * cols + c];
                 m[u] = p[c];
                 g[u] = p[(size_t)cols + c];
@@ -179,6 +192,7 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
                 acm[u] = p[(size_t)(NC + 2) * cols + c];
                 meta2[u] = p[(size_t)(NC + 3) * cols + c];
             }
+            if (wg0 == wg_lo + sub) meta_first = meta[0];
 #pragma unroll
             for (int u = 0; u < kFoldTrip; ++u) {
                 if (wg0 + kFoldSubs * u >= wg_hi) break;
@@ -189,7 +203,14 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
                 nn += n4[u];
                 add_codon(0, meta[u], cm[u]);
                 add_codon(1, meta2[u], acm[u]);
+                sr[0] += sa[u] & 0xffffu;
+                sr[1] += sa[u] >> 16;
+                sr[2] += sb[u];
             }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            if (sr[r]) atomicAdd(&sub_acc[cl * 3 + r], sr[r]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -199,6 +220,28 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
 #pragma unroll
         for (int set = 0; set < 2; ++set)
             if (cod_sum[set]) atomicAdd(&cod_acc[cl * kCodStride + cod_idx[set]], cod_sum[set]);
+    }
+    if (with_subs) {
+        __syncthreads();
+        if (sub == 0 && valid) {
+            const uint32_t meta = meta_first;  // every workgroup of such a launch counts against the same guide
+            const uint32_t k0 = meta & 3u, cidx = (meta >> 8) & 63u;
+            const int wc = col0 + c;  // window column
+#pragma unroll
+            for (int r = 0; r < 3; ++r)  // MSAColumn::IncCounts: the base read at this column
+                if (const uint32_t n = sub_acc[cl * 3 + r]) atomicAdd(&nuc_acc[cl * kNucStride + ((k0 + 1u + (uint32_t)r) & 3u)], n);
+            if (wc >= 1 && wc <= W - 3) {  // a column that can start a codon (MSARow::CodonAt's i > 0, CodingCodonAt's bound)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {  // the substitution sits in position q of the codon that starts here
+                    const int shift = 4 - 2 * q;
+                    const uint32_t kq = (cidx >> shift) & 3u;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        if (const uint32_t n = sub_acc[(cl + q) * 3 + r])
+                            atomicAdd(&cod_acc[cl * kCodStride + ((cidx & ~(3u << shift)) | (((kq + 1u + (uint32_t)r) & 3u) << shift))], n);
+                }
+            }
+        }
     }
     __syncthreads();
     const int cb = col0 + blockIdx.x * kFoldCols;  // window column of the block's column 0
@@ -233,9 +276,9 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
 __attribute__((unused)) __global__ __launch_bounds__(kFoldCols* kFoldSubs) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
                                                                              int col0, int W, uint32_t* __restrict__ nuc,
                                                                              uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
-                                                                             uint32_t* __restrict__ dev_codon)
+                                                                             uint32_t* __restrict__ dev_codon, int rows)
 {
-    fold_partials(partials, n_wg, NC, cols, col0, W, nuc, codon, dev_nuc, dev_codon);
+    fold_partials(partials, n_wg, NC, cols, col0, W, nuc, codon, dev_nuc, dev_codon, rows);
 }
 
 // the folds of a merged launch as one launch: blockIdx.z = the slab
@@ -248,7 +291,7 @@ __attribute__((unused)) __global__ __launch_bounds__(kFoldCols* kFoldSubs) void 
 {
     const int sl = blockIdx.z;
     if ((int)blockIdx.x * kFoldCols >= t.cols[sl]) return;  // the grid is as wide as the widest slab
-    fold_partials(t.partials[sl], t.n_wg[sl], NC, t.cols[sl], t.col0[sl], W, nuc, codon, nullptr, nullptr);
+    fold_partials(t.partials[sl], t.n_wg[sl], NC, t.cols[sl], t.col0[sl], W, nuc, codon, nullptr, nullptr, NC + 4);
 }
 
 

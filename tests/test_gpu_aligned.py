@@ -216,3 +216,32 @@ def test_more_reads_than_one_launch_counts(ctx):
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     assert int(got[0].sum()) == wl.n_reads * wl.W
     al.close()
+
+
+@pytest.mark.parametrize("name,n", [("hiv_mix_200k", 3000), ("amp20k_10m", 600)])
+def test_wide_windows_go_slab_by_slab(ctx, name, n):
+    """Windows of more than 126 words (9719 and 20000 columns): one launch per slab of <= 126 words, each loading only
+    its words of every read; the oracle on the same reads, and the read-space kernels."""
+    wl = synth.workload(name, n_reads=n)
+    src = device.synth_device(ctx, wl, 0, n)
+    al = device.align(ctx, src, NONE, wl.win_begin0)
+    m = orc.Msa(wl.host_reads(0, n))
+    W, b0 = wl.W, wl.win_begin0
+    assert (m.begin1 - 1, m.W) == (b0, W)
+    got = counts(ctx, al, NONE, b0, W, abi.MSQ_PILEUP_ROWS)
+    assert np.array_equal(got[0], m.nuc_counts()) and np.array_equal(got[1], m.codon_counts())
+    # staggered reads cut by a window that starts 320 columns further right: the deferred window error
+    nuc, codon = device.alloc_counts(ctx, W)
+    abi.check(abi.lib().msq_pileup(ctx.h, al.view, NONE, b0 + 320, W - 320, nuc.data_ptr(), codon.data_ptr(), abi.MSQ_PILEUP_ROWS))
+    assert abi.lib().msq_pileup_check(ctx.h) == abi.MSQ_ERR_WINDOW
+    al.close()
+
+
+def test_wide_window_large_sample(ctx):
+    wl = synth.workload("hiv_mix_200k", n_reads=40000, minor_frac=0.05, sub=0.002)
+    src = device.synth_device(ctx, wl, 0, wl.n_reads)
+    al = device.align(ctx, src, NONE, wl.win_begin0)
+    want = device.pileup(ctx, src, NONE, wl.win_begin0, wl.W, mode=abi.MSQ_PILEUP_STREAM)
+    got = device.pileup(ctx, al, NONE, wl.win_begin0, wl.W, mode=abi.MSQ_PILEUP_ROWS)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    al.close()
