@@ -480,6 +480,10 @@ int msq_rows_decode(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_
  * library does not.) */
 int msq_debug_merged_launches(void);
 int msq_debug_phase_lookups(void);
+/* tools: event counts of the aligned-set pileup kernel since the last call -- {queue entries, drains, nucleotide atomics,
+ * codon atomics, alt-haplotype LDS adds, isolated-substitution LDS adds, 0, 0}; all zero unless the library was built
+ * with -DMSQ_ROWS_EXP=4.  No counterpart in the reference. */
+int msq_debug_rows_counters(unsigned long long* out8);
 /* Device memory the context has allocated so far and still holds (scratch, msq_pileup_step's deviation matrix, the
  * log-factorial table): a call that promises not to allocate (msq_pileup_noalloc) leaves it unchanged. */
 uint64_t msq_debug_ctx_device_bytes(const msq_ctx* ctx);

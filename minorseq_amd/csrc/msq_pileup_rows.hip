@@ -26,10 +26,28 @@
 
 namespace {
 
+// MSQ_ROWS_EXP: compile-time timing experiments only (make EXTRA=-DMSQ_ROWS_EXP=n); any non-zero value gives WRONG counts.
+// bit 0: the drain issues no global atomics; bit 1: nothing is pushed on the deviation queue; bit 2 (right counts):
+// the kernel counts its queue entries, drains and global atomics into rows_dbg (read it with a debugger build's
+// hipMemcpyFromSymbol; tools only).
+#ifndef MSQ_ROWS_EXP
+#define MSQ_ROWS_EXP 0
+#endif
+// MSQ_ROWS_PAIR: 0 = batches drawn from the role's LDS counter; 1 = a fixed sequence per wave, the same for the two roles'
+// waves 2k, 2k + 1; 2 = the same, and neither wave of a pair runs more than one batch ahead of the other
+#ifndef MSQ_ROWS_PAIR
+#define MSQ_ROWS_PAIR 0
+#endif
+#if MSQ_ROWS_EXP & 4
+__device__ unsigned long long rows_dbg[8];  // entries, drains, nucleotide atomics, codon atomics, LDS alt adds, LDS substitution adds
+#define ROWS_DBG(i, n) dbg[i] += (n)
+#else
+#define ROWS_DBG(i, n) ((void)0)
+#endif
 constexpr int kRowsWaves = 12;     // waves per workgroup (one workgroup per CU, 3 waves per SIMD: 168 VGPRs, nothing spills)
 constexpr int kQueueCap = 384;     // entries of a wave's deviation queue: 16 B of planes + a 4-byte tag each
 constexpr int kQueueRoom = 128;    // two reads add at most this many entries: drained when fewer slots are left
-constexpr int kQueueDrainAt = 64;  // at the end of a batch: drain when at least this many entries wait (a full wave of lanes)
+constexpr int kQueueDrainAt = 192; // at the end of a batch: drain when at least this many entries wait (three full waves of lanes: a drain ends with vmcnt(0), a bubble in the load pipeline)
 constexpr int kLanesPerPass = 63;  // productive lanes of a wave; lane 63 lends the next word
 
 struct RowsArgs {
@@ -60,6 +78,10 @@ __device__ __forceinline__ uint32_t dpp_next_lane(uint32_t v)  // lane i <- lane
 {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
+__device__ __forceinline__ uint32_t dpp_prev_lane(uint32_t v)  // lane i <- lane i - 1, lane 0 <- 0 (wave_shr:1)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
 __device__ __forceinline__ uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 // The eight reads of a batch as the loads need them, lane i = read i: the first three words of the read's buffer
@@ -88,7 +110,8 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
     uint4* const q4 = reinterpret_cast<uint4*>(lds + (size_t)wave * (kQueueCap * 5));
     uint32_t* const qt = reinterpret_cast<uint32_t*>(q4 + kQueueCap);
     uint32_t* const draw_ctr = lds + (size_t)NWV * (kQueueCap * 5);  // [0], [1]: the roles' batch counters; [2], [3]: the bounds
-    uint32_t* const gl = draw_ctr + 4;
+    uint32_t* const prog = draw_ctr + 4;  // [16]: the batch each wave is at (pairs of waves keep in step)
+    uint32_t* const gl = prog + 16;
     uint32_t* const gl2 = gl + 4 * (G + 2);
     uint32_t* const altc = gl2 + 4 * (G + 2);  // [G * 32]: alt nucleotide count | alt codon count << 16
     // isolated substitutions per column, by the rank r of the base read ((guide's code + 1 + r) & 3): [G * 32] r0 | r1 << 16,
@@ -96,9 +119,12 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
     uint32_t* const subA = altc + G * 32;
     uint32_t* const subB = subA + G * 32;
     uint32_t my_err = 0;
+#if MSQ_ROWS_EXP & 4
+    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
     // ---- set-up: the guide words of the window from the set's guide (grid word = window word + word0)
-    if (tid < 4) draw_ctr[tid] = 0;
+    if (tid < 20) draw_ctr[tid] = 0;
     for (int i = tid; i < (G + 2) * 4; i += T) {
         const int w = i >> 2, k = i & 3;
         const long long gw = (long long)a.word0 + a.slab_w0 + w;  // words G, G + 1: the next slab's first words, or nothing
@@ -131,6 +157,10 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
     const int gw_ = min(lw, G + 1);
     const uint32_t gx = gl[gw_ * 4], gy = gl[gw_ * 4 + 1], gz = gl[gw_ * 4 + 2];
     const int32_t lw16 = cg << 4;
+    // the next word's columns 2, 3 go into a queue entry (isolated substitutions in the next word's first columns change
+    // codons of this word) -- not at a seam: the word behind lane 62 and behind a slab's last word is counted by another
+    // wave or launch, whose view of this word's last columns is empty (its lane 0 has no previous lane)
+    const uint32_t mh_keep = (lane == kLanesPerPass - 1 || lw == G - 1) ? 0u : 3u;
     uint32_t seen = 0;
     uint32_t cnt[NC][kLevels];
 #pragma unroll
@@ -144,8 +174,12 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
     auto draw = [&]() -> uint32_t {
         uint32_t t = 0xffffffffu;
         if (n_taken < (uint32_t)kMaxBatchesPerWave) {
+#if MSQ_ROWS_PAIR
+            t = n_taken * (uint32_t)waves_per_role + (uint32_t)wave_in_role;
+#else
             if (lane == 0) t = __hip_atomic_fetch_add(&draw_ctr[role], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             t = uni(t);
+#endif
             n_taken = uni(n_taken + 1u);
         }
         const uint32_t b = t == 0xffffffffu ? 0xffffffffu : t * nwg + wg;
@@ -196,7 +230,9 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
     auto drain = [&]() {
         wave_sync();  // the entries other lanes wrote
         const uint32_t nq = uni(qn);
+        if (lane == 0) ROWS_DBG(1, 1);
         for (uint32_t e = lane; e < nq; e += 64) {
+            ROWS_DBG(0, 1);
             const uint4 lo = q4[e];  // V, X, B0, B1 of the word
             const uint32_t tag = qt[e];
             const int cgq = (int)(tag & 0xffu);       // word of the slab: guide words and LDS tables
@@ -227,19 +263,28 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
                 bits &= bits - 1;
                 __hip_atomic_fetch_add(&altc[lbase + j], ((nd_alt >> j) & 1u) | (((cd_alt >> j) & 1u) << 16), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+                ROWS_DBG(4, 1);
             }
             // An ISOLATED substitution -- a base that differs from the guide's while the two columns on either side of
-            // it, all inside this word, match the guide (what a sequencing error looks like) -- changes exactly one
+            // it match the guide (what a sequencing error looks like) -- changes exactly one
             // nucleotide bin and the three codons that hold it, each in one position: it is counted ONCE, in LDS, by its
             // column and the rank of the base read, and the fold turns the sums into the four bins.  Returnless global
             // atomics run at ~26e9 / s on the whole chip; at the reference's error rate (0.05 %) the four atomics per
             // substitution were a third of the kernel's time, and uniform noise of 2 % cost 20 x a clean sample.
             uint32_t nd_rest = nd & ~nd_alt, cd_rest = cd & ~cd_alt;
-            bits = nd_rest & 0x3ffffffcu;  // columns 2 .. 29 of the word: all five columns and three codon starts inside it
+            // match bits of columns -2 .. 35 of the word (bit = column + 2): the neighbours' as the tag brought them
+            const uint32_t mh4 = m_hi | (((tag >> 16) & 3u) << 2);
+            const uint64_t M = (uint64_t)((tag >> 14) & 3u) | ((uint64_t)m_lo << 2) | ((uint64_t)mh4 << 34);
+            // the next word's isolated substitutions in its columns 0 and 1 (its own entry counts them: the same bits, the
+            // same test) change this word's codons at columns 30, 31 / 31: the fold adds those as well
+            const uint32_t fdev = hv & ~m_hi & ~am_hi;
+            if ((fdev & 1u) && (m_lo >> 30) == 3u && (mh4 & 6u) == 6u) cd_rest &= ~(3u << 30);
+            if ((fdev & 2u) && (m_lo >> 31) && (mh4 & 0xdu) == 0xdu) cd_rest &= ~(1u << 31);
+            bits = nd_rest;
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
-                if (((m_lo >> (j - 2)) & 0x1bu) != 0x1bu) continue;  // a neighbour deviates, is a gap or is not there
+                if (((uint32_t)(M >> j) & 0x1bu) != 0x1bu) continue;  // a neighbour deviates, is a gap or is not there
                 const uint32_t code = ((lo.z >> j) & 1u) | (((lo.w >> j) & 1u) << 1);
                 const uint32_t g = ((gl_lo.y >> j) & 1u) | (((gl_lo.z >> j) & 1u) << 1);
                 const uint32_t r = (code - g - 1u) & 3u;  // 0 .. 2: code != g
@@ -248,22 +293,31 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
                 else
                     __hip_atomic_fetch_add(&subB[lbase + j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 nd_rest &= ~(1u << j);
-                cd_rest &= ~(7u << (j - 2));  // the codons that start at j - 2, j - 1, j: the fold adds them where they count
+                ROWS_DBG(5, 1);
+                cd_rest &= ~(uint32_t)((7ull << j) >> 2);  // the codons that start at j - 2, j - 1, j (those of this word): the fold adds them where they count
             }
             bits = nd_rest | nn;  // disjoint: nd lies in V, nn in X
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
                 const uint32_t code = ((nn >> j) & 1u) ? 5u : (((lo.z >> j) & 1u) | (((lo.w >> j) & 1u) << 1));
+                ROWS_DBG(2, 1);
+#if !(MSQ_ROWS_EXP & 1)
                 atomicAdd(&a.nuc[(uint32_t)(cbase + j) * 6u + code], 1u);  // MSAColumn::IncCounts, MSA.inl:66
+#endif
             }
             bits = cd_rest;
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
                 const uint32_t t0 = funnel(lo.z, hb0, j) & 7u, t1 = funnel(lo.w, hb1, j) & 7u;
+                ROWS_DBG(3, 1);
                 const uint32_t idx = ((t1 & 1u) << 5) | ((t0 & 1u) << 4) | ((t1 & 2u) << 2) | ((t0 & 2u) << 1) | ((t1 & 4u) >> 1) | ((t0 & 4u) >> 2);
+#if !(MSQ_ROWS_EXP & 1)
                 atomicAdd(&a.codon[(uint32_t)(cbase + j) * 64u + idx], 1u);  // ++codons[codon], MSA.cpp:132
+#else
+                if (idx == 77u) my_err |= DEVERR_RANGE;
+#endif
             }
         }
         qn = 0;
@@ -294,11 +348,13 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
         if (COUNT_N) x[NC - 1] = nn;
         const uint32_t dev = (V & ~m) | (cv & ~cm) | (COUNT_N ? 0u : nn);
         const uint64_t bal = __ballot(dev != 0) & actb;  // lanes that count (not the lending lane, not lanes past the window)
-        if (bal) {  // wave-uniform
+        if (bal && !(MSQ_ROWS_EXP & 2)) {  // wave-uniform
             const bool has = (bal >> lane) & 1u;
             // the next word's first two columns (codons reach into them), for every lane: all lanes are active here
             const uint32_t b0 = w.x & (V | X), b1 = w.y & V;
-            const uint32_t tag = (uint32_t)lw | ((v_hi & 3u) << 8) | ((dpp_next_lane(b0) & 3u) << 10) | ((dpp_next_lane(b1) & 3u) << 12);
+            // and the match bits around the word: the previous word's columns 30, 31, the next word's columns 2, 3
+            const uint32_t tag = (uint32_t)lw | ((v_hi & 3u) << 8) | ((dpp_next_lane(b0) & 3u) << 10) | ((dpp_next_lane(b1) & 3u) << 12) |
+                                 ((dpp_prev_lane(m) >> 30) << 14) | (((m_hi >> 2) & mh_keep) << 16);
             const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, qn));
             if (has) {
                 q4[pos] = make_uint4(V, X, b0, b1);
@@ -333,7 +389,19 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
             atomicMax(&draw_ctr[3], k_hi);
         }
     }
+#if MSQ_ROWS_PAIR == 2
+    uint32_t it = 0;
+#endif
     while (b_cur != 0xffffffffu) {
+#if MSQ_ROWS_PAIR == 2
+        // The two waves of a pair load neighbouring bytes of the same rows -- the 128-byte lines at the seam of the roles'
+        // ranges are fetched by both.  Kept within one batch of each other, the second finds them in the L2.
+        if (n_roles == 2) {
+            it = uni(it + 1u);
+            if (lane == 0) __hip_atomic_store(&prog[wave], it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (uni(__hip_atomic_load(&prog[wave ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + 1u < it) __builtin_amdgcn_s_sleep(1);
+        }
+#endif
         uint32_t c4[2][NC], c8[NC];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -380,6 +448,9 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
         fetch_table(b_nn, f_lo, f_hi, f_rs);
     }
     if (qn) drain();
+#if MSQ_ROWS_PAIR == 2
+    if (lane == 0) __hip_atomic_store(&prog[wave], 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 
     // ---- flush: per column the guide's and the alt haplotype's bins (meta), the alt counts; then the waves' bit-sliced
     // counters added up while still bit-sliced, one wave per (counter, role), the sum transposed and stored
@@ -462,12 +533,29 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
         for (int r = 0; r < n_roles; ++r) round(r, r + 1);
     }
     if (my_err) atomicOr(a.err, my_err);
+#if MSQ_ROWS_EXP & 4
+    for (int i = 0; i < 8; ++i)
+        if (dbg[i]) atomicAdd(&rows_dbg[i], dbg[i]);
+#endif
 }
 
 typedef void (*rows_kernel_fn)(RowsArgs);
 rows_kernel_fn pick_rows_kernel(bool many_n) { return many_n ? pileup_rows_kernel<true> : pileup_rows_kernel<false>; }
 
 }  // namespace
+
+// tools: the kernel's event counts since the last call (zeros unless built with MSQ_ROWS_EXP & 4)
+extern "C" int msq_debug_rows_counters(unsigned long long* out8)
+{
+#if MSQ_ROWS_EXP & 4
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    MSQ_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(rows_dbg), sizeof(zero)));
+    MSQ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rows_dbg), zero, sizeof(zero)));
+#else
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+#endif
+    return MSQ_OK;
+}
 
 // The pileup of an aligned set inside [win_begin0, win_begin0 + W).  *handled = false: not this kernel's case (no guide,
 // a window off the set's word grid, exotic symbols, QV planes a threshold would read) -- the
@@ -536,7 +624,7 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
                 n_wg = (int)((n_batches + wr - 1) / wr);
             }
             const int w = wr * n_roles;
-            const size_t stream_lds = (size_t)w * kQueueCap * 20 + 16 + (size_t)(G + 2) * 32 + (size_t)G * 128 * 3;
+            const size_t stream_lds = (size_t)w * kQueueCap * 20 + 80 + (size_t)(G + 2) * 32 + (size_t)G * 128 * 3;
             const size_t slab_lds = (size_t)NC * wr * kLevels * 256;  // one role's levels in the flush
             const bool flush_wide = slab_lds * n_roles <= 160 * 1024 - 512;
             const size_t lds = std::max(stream_lds, flush_wide ? slab_lds * n_roles : slab_lds);

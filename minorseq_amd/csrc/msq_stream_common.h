@@ -160,10 +160,10 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
         // guide's codon, set 1 = the alt haplotype's)
         uint32_t cod_sum[2] = {0, 0};
         int cod_idx[2] = {-1, -1};
-        // isolated substitutions (rows NC + 4, NC + 5) of this column, unpacked and summed.  A block is one 32-column
-        // word and an isolated substitution sits in columns 2 .. 29 of its word, so the codons it changes (they start
-        // up to two columns before it) all start in the same block: sub_acc's two margin entries stay zero
-        uint32_t sr[3] = {0, 0, 0};
+        // isolated substitutions (rows NC + 4, NC + 5) of this column, unpacked and summed; the codons one changes start
+        // up to two columns before it: the threads of columns 0 and 1 also sum the next block's columns 0 and 1
+        uint32_t sr[3] = {0, 0, 0}, sr2[3] = {0, 0, 0};
+        const bool margin = with_subs && cl < 2 && c + kFoldCols < cols;
         auto add_codon = [&](int set, uint32_t meta, uint32_t n) {
             if (!n) return;
             const int idx = (int)((meta >> 8) & 63u);
@@ -208,9 +208,29 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
                 sr[2] += sb[u];
             }
         }
+        if (margin) {  // a trip of its own (two lanes of 32): kept out of the main trip, whose registers are full
+            for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += kFoldSubs * kFoldTrip) {
+                uint32_t sa[kFoldTrip], sb[kFoldTrip];
+#pragma unroll
+                for (int u = 0; u < kFoldTrip; ++u) {
+                    const int wg = min(wg0 + kFoldSubs * u, wg_hi - 1);
+                    const uint32_t* p = partials + (size_t)wg * rows * cols + c + kFoldCols;
+                    const bool in = wg0 + kFoldSubs * u < wg_hi;
+                    sa[u] = in ? p[(size_t)(NC + 4) * cols] : 0u;
+                    sb[u] = in ? p[(size_t)(NC + 5) * cols] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < kFoldTrip; ++u) {
+                    sr2[0] += sa[u] & 0xffffu;
+                    sr2[1] += sa[u] >> 16;
+                    sr2[2] += sb[u];
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             if (sr[r]) atomicAdd(&sub_acc[cl * 3 + r], sr[r]);
+            if (sr2[r]) atomicAdd(&sub_acc[(kFoldCols + cl) * 3 + r], sr2[r]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
