@@ -480,6 +480,13 @@ int msq_rows_decode(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_
  * library does not.) */
 int msq_debug_merged_launches(void);
 int msq_debug_phase_lookups(void);
+/* tests and tools: the two launcher switches the library otherwise reads from the environment once, when the context is
+ * made -- MSQ_NO_MERGE (a launch per column slab instead of one merged launch) and MSQ_CARRIER_MIN_BATCHES (from how many
+ * batches per wave on a launch of the read-space kernel takes the carrier rule; < 0: the default).  No counterpart in the
+ * reference. */
+#define MSQ_TUNE_NO_MERGE 1
+#define MSQ_TUNE_CARRIER_MIN_BATCHES 2
+int msq_debug_tune(msq_ctx* ctx, int key, long long value);
 /* tools: event counts of the aligned-set pileup kernel since the last call -- {queue entries, drains, nucleotide atomics,
  * codon atomics, alt-haplotype LDS adds, isolated-substitution LDS adds, 0, 0}; all zero unless the library was built
  * with -DMSQ_ROWS_EXP=4.  No counterpart in the reference. */

@@ -130,6 +130,7 @@ _SIGNATURES = {
     "msq_rows_decode": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P]),
     "msq_debug_merged_launches": (C.c_int, []),
     "msq_debug_phase_lookups": (C.c_int, []),
+    "msq_debug_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong]),
     "msq_debug_rows_counters": (C.c_int, [C.POINTER(C.c_ulonglong)]),
     "msq_debug_ctx_device_bytes": (C.c_uint64, [_P]),
     "msq_phase_codons": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_int32, _P, _P]),

@@ -1,6 +1,10 @@
 // msq_ctx.hip -- context, error text, device-memory helpers, log-factorial table.
 #include "msq_internal.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -54,7 +58,33 @@ extern "C" int msq_ctx_create(int device, msq_ctx** out)
         delete c;
         return rc;
     }
+    c->no_merge = std::getenv("MSQ_NO_MERGE") != nullptr;
+    if (const char* v = std::getenv("MSQ_CARRIER_MIN_BATCHES")) c->carrier_min_batches = (int64_t)strtoll(v, nullptr, 10);
     *out = c;
+    return MSQ_OK;
+}
+
+extern "C" int msq_debug_tune(msq_ctx* ctx, int key, long long value)
+{
+    if (!ctx) return msq_fail(MSQ_ERR_ARG, "msq_debug_tune: ctx is NULL");
+    switch (key) {
+    case MSQ_TUNE_NO_MERGE: ctx->no_merge = value != 0; return MSQ_OK;
+    case MSQ_TUNE_CARRIER_MIN_BATCHES: ctx->carrier_min_batches = (int64_t)value; return MSQ_OK;
+    default: return msq_fail(MSQ_ERR_ARG, "msq_debug_tune: unknown key %d", key);
+    }
+}
+
+int msq_ensure_dynamic_lds(int device, const void* kernel, size_t lds)
+{
+    if (lds <= 48 * 1024) return MSQ_OK;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> set;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = set[std::make_pair(device, kernel)];
+    if (lds > have) {
+        MSQ_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        have = lds;
+    }
     return MSQ_OK;
 }
 

@@ -54,7 +54,14 @@ struct msq_ctx {
     std::vector<hipEvent_t> ev_begin, ev_end, ev_path_end;
     int ev_used = 0, ev_stride = 1, ev_calls = 0;
     bool ev_open = false, ev_path_open = false;
+    // switches read from the environment ONCE, when the context is made (MSQ_NO_MERGE, MSQ_CARRIER_MIN_BATCHES), or set
+    // with msq_debug_tune: the launchers look here, never at the environment
+    bool no_merge = false;
+    int64_t carrier_min_batches = -1;  // < 0: the kernel's default
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when `lds` exceeds what was last set for this kernel on this device
+int msq_ensure_dynamic_lds(int device, const void* kernel, size_t lds);
 
 // Packed reads resident in HBM and owned by the library: the eight arrays of msq_packed_reads (ref_start, ref_end,
 // group_off, bop, qual, delqv, subqv, insqv; absent planes NULL) and the view over them.

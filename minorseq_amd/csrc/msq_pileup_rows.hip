@@ -584,6 +584,10 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
     const bool many_n = (R.flags & MSQ_READS_QV_BAKED) != 0;
     const int NC = many_n ? 4 : 3;
 
+    // msq_pileup_noalloc: partials that would not fit the built-in buffer -> the read-space kernel (7 rows per workgroup
+    // instead of 9) takes the call
+    if (fixed_partials && (size_t)ctx->n_cu * (NC + 6) * Gslab * 32 * 4 > fixed_bytes) return MSQ_OK;
+
     RowsArgs a;
     memset(&a, 0, sizeof(a));
     a.ref_start = R.ref_start;
@@ -647,12 +651,7 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
                 msq_timing_mark_begin(ctx);
                 marked = true;
             }
-            static size_t lds_set[2] = {0, 0};  // per kernel the largest dynamic LDS size set so far
-            const int ki = many_n ? 1 : 0;
-            if (lds > 48 * 1024 && lds > lds_set[ki]) {
-                MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                lds_set[ki] = lds;
-            }
+            if (int rc = msq_ensure_dynamic_lds(ctx->device, reinterpret_cast<const void*>(kern), lds)) return rc;
             hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
             if (slab + 1 == n_slabs && hi == R.n_reads) msq_timing_mark_end(ctx);
             MSQ_HIP(hipGetLastError());

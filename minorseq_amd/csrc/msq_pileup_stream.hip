@@ -1315,7 +1315,7 @@ static int stream_launch_merged(msq_ctx* ctx, const msq_packed_reads* const* set
                                 uint32_t* fixed_partials, size_t fixed_bytes, bool* handled)
 {
     *handled = false;
-    if (getenv("MSQ_NO_MERGE")) return MSQ_OK;
+    if (ctx->no_merge) return MSQ_OK;
     const int Gtot = (W + 31) / 32;
     int n_slabs = 0, Gslab = 0;
     msq_slab_layout(W, slab_words, &n_slabs, &Gslab);
@@ -1377,8 +1377,7 @@ static int stream_launch_merged(msq_ctx* ctx, const msq_packed_reads* const* set
     }
     share[biggest] += n_wg - given;
     if (share[biggest] < 1) return MSQ_OK;
-    const char* env_min = getenv("MSQ_CARRIER_MIN_BATCHES");
-    const uint64_t min_batches = env_min ? (uint64_t)strtoull(env_min, nullptr, 10) : (uint64_t)kCarrierMinBatches;
+    const uint64_t min_batches = ctx->carrier_min_batches >= 0 ? (uint64_t)ctx->carrier_min_batches : (uint64_t)kCarrierMinBatches;
     // rounds: a wave's counters hold kMaxBatchesPerWave batches, so a slab with more reads than its workgroups can count
     // takes the reads in `rounds` equal ranges, one merged launch (+ folds) per range
     uint64_t rounds = 1;
@@ -1416,8 +1415,7 @@ static int stream_launch_merged(msq_ctx* ctx, const msq_packed_reads* const* set
     a.err = ctx->d_err;
     for (int k = 0; k < 4; ++k) a.thr[k] = -1;
     pileup_kernel_fn kern = pick_merged_kernel(passes, many_n, idx);
-    if (lds > 48 * 1024)
-        MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (int rc = msq_ensure_dynamic_lds(ctx->device, reinterpret_cast<const void*>(kern), lds)) return rc;
     msq_timing_mark_begin(ctx);
     for (uint64_t round = 0; round < rounds; ++round) {
         uint32_t wg_first = 0;
@@ -1616,9 +1614,9 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
             a.n_batches = n_batches;
             // the carrier rule costs two workgroup barriers and a second pass over the counts (~4 us per launch): for
             // launches of at least kCarrierMinBatches batches per wave
-            // (MSQ_CARRIER_MIN_BATCHES in the environment overrides the threshold: the tests run small sets through both rules)
-            const char* env_min = getenv("MSQ_CARRIER_MIN_BATCHES");
-            const uint64_t min_batches = env_min ? (uint64_t)strtoull(env_min, nullptr, 10) : (uint64_t)kCarrierMinBatches;
+            // (MSQ_CARRIER_MIN_BATCHES in the environment when the context is made, or msq_debug_tune, overrides the
+            // threshold: the tests run small sets through both rules)
+            const uint64_t min_batches = ctx->carrier_min_batches >= 0 ? (uint64_t)ctx->carrier_min_batches : (uint64_t)kCarrierMinBatches;
             a.carrier = (!MSQ_NO_CARRIER && n_batches >= min_batches * w * n_wg) ? 1u : 0u;
             if (fused) {  // deviations into the context's matrix; the fold stores the sum and clears that matrix again
                 a.nuc = fused->d_dev;
@@ -1631,8 +1629,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
                 msq_timing_mark_begin(ctx);
                 marked = true;
             }
-            if (lds > 48 * 1024)
-                MSQ_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            if (int rc = msq_ensure_dynamic_lds(ctx->device, reinterpret_cast<const void*>(kern), lds)) return rc;
             hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
             if (!phase && last_slab && hi == R.n_reads) msq_timing_mark_end(ctx);
             MSQ_HIP(hipGetLastError());

@@ -245,3 +245,28 @@ def test_wide_window_large_sample(ctx):
     got = device.pileup(ctx, al, NONE, wl.win_begin0, wl.W, mode=abi.MSQ_PILEUP_ROWS)
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     al.close()
+
+
+def test_noalloc_on_an_aligned_set_too_wide_for_its_built_in_partials(ctx):
+    """4000 columns = 125 words: the aligned-set kernel's partials (9 rows per workgroup) exceed msq_pileup_noalloc's
+    built-in 32 MiB, the read-space kernel's (7 rows) fit -- the call is served by that kernel, allocates nothing and
+    gives the same counts."""
+    reads = cases.random_reads(77, 700, 4000, p_ins=0.01, p_sub=0.01, p_del=0.01)
+    src = device.upload(device.pack_host(reads), ctx.device, ctx=ctx)
+    b, e = device.window_bounds(ctx, src)
+    W = e - b
+    assert 3900 < W <= 4096
+    al = device.align(ctx, src, NONE, b)
+    want = device.pileup(ctx, al, NONE, b, W, mode=abi.MSQ_PILEUP_ROWS)
+    L = abi.lib()
+    nuc, codon = device.alloc_counts(ctx, W)
+    abi.check(L.msq_pileup_noalloc(ctx.h, al.view, NONE, b, W, nuc.data_ptr(), codon.data_ptr()))  # loads the code
+    held = L.msq_debug_ctx_device_bytes(ctx.h)
+    free = torch.cuda.mem_get_info()[0]
+    nuc.zero_()
+    codon.zero_()
+    abi.check(L.msq_pileup_noalloc(ctx.h, al.view, NONE, b, W, nuc.data_ptr(), codon.data_ptr()))
+    abi.check(L.msq_pileup_check(ctx.h))
+    assert L.msq_debug_ctx_device_bytes(ctx.h) == held and torch.cuda.mem_get_info()[0] == free
+    assert torch.equal(nuc, want[0]) and torch.equal(codon, want[1])
+    al.close()

@@ -20,9 +20,11 @@ def ctx():
 
 
 @pytest.fixture(params=["0", "1000000"], ids=["carrier", "any-runner-up"])
-def rule(request, monkeypatch):
-    monkeypatch.setenv("MSQ_CARRIER_MIN_BATCHES", request.param)
-    return request.param
+def rule(request, ctx):
+    # MSQ_TUNE_CARRIER_MIN_BATCHES (what MSQ_CARRIER_MIN_BATCHES sets when a context is made)
+    abi.check(abi.lib().msq_debug_tune(ctx.h, 2, int(request.param)))
+    yield request.param
+    abi.check(abi.lib().msq_debug_tune(ctx.h, 2, -1))
 
 
 def check(ctx, dr, thr, b, W):

@@ -203,3 +203,49 @@ def test_amp20k_many_batches_per_slab(ctx):
         return out
     oracle_tie_in(ctx, wl, thr, 400, n, (N, Cc), rest_through_partition)
     assert check_cells(ctx, wl, codon, Cc, n, b0) > 20000
+
+
+def test_amp20k_one_gpu_shard_of_config_5(ctx):
+    """BASELINE config #5 as one GPU of eight holds it: 1.25e6 reads x 20000 columns (2.5e10 bases).  The column-slab
+    partition in merged launches (the reads of a slab exceed what its workgroups' counters hold: two rounds), the
+    aligned set slab by slab, and the simple kernel give the same matrices; properties; the oracle on a 200-read prefix.
+    Skipped when the card has not 100 GB free."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 100 * 2**30:
+        pytest.skip("config #5's one-GPU shard needs ~100 GB of free HBM, this card has %.0f GB" % (free / 2**30))
+    wl = synth.workload("amp20k_10m", n_reads=1250000)
+    n, W, b0 = wl.n_reads, wl.W, wl.win_begin0
+    thr = abi.QvThresholds.make()
+    dr = device.synth_device(ctx, wl, 0, n)
+    assert device.window_bounds(ctx, dr) == (b0, b0 + W)
+    part = device.Partition(ctx, dr, b0, W)
+    assert part.n_slabs == 5
+    before = abi.lib().msq_debug_merged_launches()
+    nuc, codon = part.pileup(thr)
+    assert abi.lib().msq_debug_merged_launches() - before >= 1  # the merged path took it (two rounds: 1.25e6 reads per slab)
+    part.close()
+    al = device.align(ctx, dr, thr, b0)
+    nuc_a, codon_a = device.pileup(ctx, al, thr, b0, W, mode=abi.MSQ_PILEUP_ROWS)
+    assert torch.equal(nuc, nuc_a) and torch.equal(codon, codon_a)
+    del nuc_a, codon_a
+    nuc_s, codon_s = device.pileup(ctx, dr, thr, b0, W, mode=abi.MSQ_PILEUP_SIMPLE)
+    assert torch.equal(nuc, nuc_s) and torch.equal(codon, codon_s)
+    del dr, nuc_s, codon_s
+    N, Cc = as_np(nuc, codon, W)
+    check_properties(N, Cc, n, W)
+    assert (Cc[1:W - 2].sum(1) > 0.97 * n).all()
+    # counts(all) - counts(reads 200 ..) == oracle(first 200); the rest through the aligned set's kernel
+    k = 200
+    rest_al = device.align(ctx, device.synth_device(ctx, wl, k, n - k), thr, b0)
+    rn, rc = as_np(*device.pileup(ctx, rest_al, thr, b0, W, mode=abi.MSQ_PILEUP_ROWS), W)
+    m = orc.Msa(wl.host_reads(0, k))
+    assert (N - rn == m.nuc_counts()).all() and (Cc - rc == m.codon_counts()).all()
+    # additivity over the shard rule: the halves of this shard add up to it
+    al.close()
+    rest_al.close()
+    half = n // 2
+    h0 = device.align(ctx, device.synth_device(ctx, wl, 0, half), thr, b0)
+    n0, c0 = device.pileup(ctx, h0, thr, b0, W)
+    h1 = device.align(ctx, device.synth_device(ctx, wl, half, n - half), thr, b0)
+    device.pileup(ctx, h1, thr, b0, W, nuc=n0, codon=c0)
+    assert torch.equal(nuc, n0) and torch.equal(codon, c0)

@@ -12,10 +12,15 @@ pytestmark = pytest.mark.gpu
 NONE = abi.QvThresholds.make()
 
 
+LIVE = []
+
+
 @pytest.fixture(scope="module")
 def ctx():
     c = device.Ctx(0)
+    LIVE.append(c)
     yield c
+    LIVE.remove(c)
     c.close()
 
 
@@ -23,17 +28,25 @@ def merged_launches():
     return abi.lib().msq_debug_merged_launches()
 
 
-def both_ways(monkeypatch, run, expect_merged=True):
+TUNE_NO_MERGE = 1  # MSQ_TUNE_NO_MERGE
+
+
+def both_ways(monkeypatch, run, expect_merged=True, ctx=None):
     """run() with the merged launch and with one launch per slab."""
     before = merged_launches()
     got = run()
     took = merged_launches() - before
     assert (took > 0) == expect_merged, took
-    monkeypatch.setenv("MSQ_NO_MERGE", "1")
+    # the switch the library reads from MSQ_NO_MERGE when a context is made, set on the contexts alive in this module
+    for c in LIVE:
+        abi.check(abi.lib().msq_debug_tune(c.h, TUNE_NO_MERGE, 1))
     before = merged_launches()
-    want = run()
+    try:
+        want = run()
+    finally:
+        for c in LIVE:
+            abi.check(abi.lib().msq_debug_tune(c.h, TUNE_NO_MERGE, 0))
     assert merged_launches() == before
-    monkeypatch.delenv("MSQ_NO_MERGE")
     for x, y in zip(got, want):
         assert torch.equal(x, y)
     return got
