@@ -95,8 +95,13 @@ typedef struct msq_packed_reads {
     const uint32_t* gcol;       /* [n_groups] or NULL: the group column index (msq_reads_index) */
     const uint32_t* guide;      /* [guide_words][8] or NULL: the set's guide / alt haplotype (msq_reads_align) */
     uint32_t guide_words;
-    uint32_t reserved;
+    uint32_t hap_count;         /* 0 or 1: no haplotype groups; 2 .. MSQ_MAX_HAPS: the reads are grouped (msq_reads_align) */
+    const uint32_t* hap_guides; /* [hap_count][guide_words][8] or NULL: a guide / alt haplotype per group */
+    const uint32_t* hap_perm;   /* [n_reads] or NULL: the reads ordered by group (group 0 first), ascending inside a group */
+    uint32_t hap_reads[8];      /* reads in each group; their sum is n_reads */
 } msq_packed_reads;
+
+#define MSQ_MAX_HAPS 8
 
 #define MSQ_READS_HAS_EXOTIC 1u /* some base uses op 1 with nucleotide code 2 or 3 */
 #define MSQ_READS_NORMALIZED 2u /* inside every group the column-consuming bases come first (see above) */
@@ -166,8 +171,12 @@ int msq_reads_bake_qv(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_q
  * another base -- a runner-up, learnt from up to 2048 reads spread evenly over the set (guide[w] = {valid, bit 0,
  * bit 1, 0, valid, alt bit 0, alt bit 1, has alt} for columns [origin + 32 w, + 32)).  A speed hint only: the pileup
  * counts cells that match the guide in registers, cells that match the alt haplotype in LDS and everything else with
- * global atomics; any guide gives the same counts.  The new set is independent of the source (the caller keeps and
- * frees that).  Synchronises. */
+ * global atomics; any guide gives the same counts.  Samples of several clones (a mixture of strains, minor populations
+ * with many variant codons) are also GROUPED BY HAPLOTYPE: the sampled reads' bases at the columns with a runner-up are
+ * clustered (on the host, <= MSQ_MAX_HAPS clusters), every read is assigned to the nearest cluster on the GPU, the
+ * reads are listed group by group (hap_perm, hap_reads) and every group gets a guide of its own (hap_guides); the
+ * pileup then counts every group against its own guide.  Again a speed hint only.  The new set is independent of the
+ * source (the caller keeps and frees that).  Synchronises. */
 int msq_reads_align(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t origin,
                     msq_packed_dev** out);
 
@@ -486,6 +495,7 @@ int msq_debug_phase_lookups(void);
  * reference. */
 #define MSQ_TUNE_NO_MERGE 1
 #define MSQ_TUNE_CARRIER_MIN_BATCHES 2
+#define MSQ_TUNE_NO_HAPS 3 /* msq_reads_align makes no haplotype groups (MSQ_NO_HAPS in the environment) */
 int msq_debug_tune(msq_ctx* ctx, int key, long long value);
 /* tools: event counts of the aligned-set pileup kernel since the last call -- {queue entries, drains, nucleotide atomics,
  * codon atomics, alt-haplotype LDS adds, isolated-substitution LDS adds, 0, 0}; all zero unless the library was built

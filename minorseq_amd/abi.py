@@ -47,7 +47,10 @@ class PackedReads(C.Structure):
         ("gcol", C.c_void_p),
         ("guide", C.c_void_p),
         ("guide_words", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("hap_count", C.c_uint32),
+        ("hap_guides", C.c_void_p),
+        ("hap_perm", C.c_void_p),
+        ("hap_reads", C.c_uint32 * 8),
     ]
 
 

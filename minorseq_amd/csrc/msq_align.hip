@@ -16,6 +16,9 @@
 
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <vector>
+
 int msq_packed_dev_index(msq_ctx* ctx, msq_packed_dev* d);
 
 namespace {
@@ -127,16 +130,18 @@ __global__ __launch_bounds__(256) void align_rows_kernel(const int32_t* __restri
 // The guide of an aligned set: block = one 32-column word of the grid.  Every sampled read that covers the word adds
 // its match bases ('=' / 'X' that are ACGT: op 0) to per-column counts in LDS; per column the most common base (the
 // smaller code among equals) and, where at least `alt_min` reads agree on another base, the most common other one.
+// With a read list (`list` != NULL: the reads of one haplotype group, `n_reads` of them) the sample is taken from the list.
 __global__ __launch_bounds__(256) void align_guide_kernel(const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ off,
                                                           const uint4* __restrict__ bop, uint64_t n_reads, int32_t origin, uint32_t sample,
-                                                          uint32_t alt_min, uint32_t* __restrict__ guide)
+                                                          uint32_t alt_min, uint32_t* __restrict__ guide, const uint32_t* __restrict__ list)
 {
     __shared__ uint32_t cnt[32][4];
     const int w = blockIdx.x, tid = threadIdx.x;
     if (tid < 128) cnt[tid >> 2][tid & 3] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < sample; i += blockDim.x) {
-        const uint64_t r = (uint64_t)i * n_reads / sample;
+        const uint64_t at = (uint64_t)i * n_reads / sample;
+        const uint64_t r = list ? (uint64_t)list[at] : at;
         const uint64_t o0 = off[r], o1 = off[r + 1];
         const long long k = (long long)w - (((long long)ref_start[r] - origin) >> 5);
         if (k < 0 || (uint64_t)k >= o1 - o0) continue;
@@ -173,12 +178,264 @@ __global__ __launch_bounds__(256) void align_guide_kernel(const int32_t* __restr
     }
 }
 
+// ---- haplotype groups.  A sample of several clones (a mixture of strains, minor populations with many variant codons)
+// strays from ONE guide in every read of a clone at every variant column; with a guide per clone every read matches its
+// own but for its errors.  At set-up: the columns where the sample supports a second base (the guide's has_alt mask) are
+// the variant columns; the sampled reads' bases there are clustered on the host (leader clustering, a few per cent of
+// tolerance for errors) into <= MSQ_MAX_HAPS haplotypes; every read of the set is assigned to the nearest one in one
+// streaming pass; the reads are listed group by group; every group learns its own guide + alt from its own reads.
+// Any grouping gives the same counts -- it only decides which cells take the cheap path.
+
+// codes[i][j] = base code (0 .. 3) of sampled read i at variant column j, 4 where it has no '=' / 'X' ACGT base
+__global__ __launch_bounds__(256) void align_sample_codes_kernel(const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ off,
+                                                                 const uint4* __restrict__ bop, uint64_t n_reads, int32_t origin, uint32_t sample,
+                                                                 const uint32_t* __restrict__ var_cols, uint32_t nvar, uint8_t* __restrict__ codes)
+{
+    const uint32_t i = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nvar) return;
+    const uint64_t r = (uint64_t)i * n_reads / sample;
+    const uint64_t o0 = off[r], o1 = off[r + 1];
+    const uint32_t c = var_cols[j];
+    const long long k = (long long)(c >> 5) - (((long long)ref_start[r] - origin) >> 5);
+    uint8_t code = 4;
+    if (k >= 0 && (uint64_t)k < o1 - o0) {
+        const uint4 q = bop[o0 + (uint64_t)k];
+        const uint32_t b = c & 31u;
+        if (((~(q.z | q.w)) >> b) & 1u) code = (uint8_t)(((q.x >> b) & 1u) | (((q.y >> b) & 1u) << 1));
+    }
+    codes[(size_t)i * nvar + j] = code;
+}
+
+// One wave per read: its mismatches against every haplotype at the variant columns; the nearest haplotype (the lower
+// index among equals) is its group.  idx[r] = r (the sort's values); counts[h] += reads of group h.
+__global__ __launch_bounds__(256) void align_assign_kernel(const int32_t* __restrict__ ref_start, const uint64_t* __restrict__ off,
+                                                           const uint4* __restrict__ bop, uint64_t n_reads, int32_t origin,
+                                                           const uint32_t* __restrict__ planes, const uint32_t* __restrict__ varmask, uint32_t words,
+                                                           int n_haps, uint8_t* __restrict__ hap_id, uint32_t* __restrict__ idx,
+                                                           uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t hist[MSQ_MAX_HAPS];
+    if (threadIdx.x < MSQ_MAX_HAPS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t r = wave; r < n_reads; r += n_waves) {
+        const uint64_t o0 = off[r], o1 = off[r + 1];
+        const long long a = ((long long)ref_start[r] - origin) >> 5;
+        uint32_t mism[MSQ_MAX_HAPS];
+#pragma unroll
+        for (int h = 0; h < MSQ_MAX_HAPS; ++h) mism[h] = 0;
+        for (uint64_t k = lane; k < o1 - o0; k += 64) {
+            const uint64_t w = (uint64_t)a + k;
+            if (w >= words) continue;
+            const uint32_t vm = varmask[w];
+            if (!vm) continue;
+            const uint4 q = bop[o0 + k];
+            const uint32_t v = ~(q.z | q.w) & vm;
+#pragma unroll
+            for (int h = 0; h < MSQ_MAX_HAPS; ++h)
+                if (h < n_haps) mism[h] += __popc(v & ((q.x ^ planes[((size_t)h * words + w) * 2]) | (q.y ^ planes[((size_t)h * words + w) * 2 + 1])));
+        }
+        uint32_t best = 0, best_d = 0xffffffffu;
+#pragma unroll
+        for (int h = 0; h < MSQ_MAX_HAPS; ++h) {
+            if (h >= n_haps) break;
+            uint32_t d = mism[h];
+            for (int s = 32; s >= 1; s >>= 1) d += __shfl_xor(d, s);
+            if (d < best_d) {
+                best_d = d;
+                best = (uint32_t)h;
+            }
+        }
+        if (lane == 0) {
+            hap_id[r] = (uint8_t)best;
+            idx[r] = (uint32_t)r;
+            atomicAdd(&hist[best], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < MSQ_MAX_HAPS && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], hist[threadIdx.x]);
+}
+
+// Leader clustering of the sampled reads' codes at the variant columns.  haps[h][j] = the group's base at variant column
+// j (0 .. 3), 255 where its members do not say; groups ordered by size, the largest first.  Returns the number of groups
+// (< 2: the sample is one population).
+int cluster_sample(const std::vector<uint8_t>& codes, uint32_t sample, uint32_t nvar, std::vector<std::vector<uint8_t>>& haps)
+{
+    haps.clear();
+    if (!nvar || sample < 8) return 1;
+    const uint32_t tol = std::max<uint32_t>(2, nvar / 40), min_members = std::max<uint32_t>(4, sample / 256);
+    const uint32_t min_cover = nvar - nvar / 10;  // reads that cover the variant columns (ragged reads do not vote)
+    struct Leader {
+        uint32_t rep;
+        std::vector<uint32_t> members;
+    };
+    std::vector<Leader> leaders;
+    for (uint32_t i = 0; i < sample; ++i) {
+        const uint8_t* row = &codes[(size_t)i * nvar];
+        uint32_t cover = 0;
+        for (uint32_t j = 0; j < nvar; ++j) cover += row[j] < 4;
+        if (cover < min_cover) continue;
+        bool joined = false;
+        for (Leader& l : leaders) {
+            const uint8_t* rep = &codes[(size_t)l.rep * nvar];
+            uint32_t d = 0;
+            for (uint32_t j = 0; j < nvar && d <= tol; ++j) d += (row[j] < 4 && rep[j] < 4 && row[j] != rep[j]);
+            if (d <= tol) {
+                l.members.push_back(i);
+                joined = true;
+                break;
+            }
+        }
+        if (!joined && leaders.size() < 64) leaders.push_back(Leader{i, {i}});
+    }
+    std::vector<const Leader*> kept;
+    for (const Leader& l : leaders)
+        if (l.members.size() >= min_members) kept.push_back(&l);
+    std::stable_sort(kept.begin(), kept.end(), [](const Leader* x, const Leader* y) { return x->members.size() > y->members.size(); });
+    if (kept.size() > MSQ_MAX_HAPS) kept.resize(MSQ_MAX_HAPS);
+    if (kept.size() < 2) return 1;
+    for (const Leader* l : kept) {
+        std::vector<uint8_t> h(nvar, 255);
+        for (uint32_t j = 0; j < nvar; ++j) {
+            uint32_t c[4] = {0, 0, 0, 0};
+            for (uint32_t m : l->members) {
+                const uint8_t v = codes[(size_t)m * nvar + j];
+                if (v < 4) ++c[v];
+            }
+            int best = 0;
+            for (int b = 1; b < 4; ++b)
+                if (c[b] > c[best]) best = b;
+            if (c[best]) h[j] = (uint8_t)best;
+        }
+        haps.push_back(std::move(h));
+    }
+    return (int)haps.size();
+}
+
 void free_dev(msq_packed_dev* d)
 {
     if (!d) return;
-    for (int j = 0; j < 10; ++j)
+    for (int j = 0; j < 12; ++j)
         if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
     delete d;
+}
+
+// The haplotype groups of an aligned set whose guide has been learnt (see above).  Leaves the view without groups when the
+// sample is one population.
+int align_haplotypes(msq_ctx* ctx, msq_packed_dev* d, int32_t origin, uint32_t sample)
+{
+    msq_packed_reads& v = d->view;
+    const uint64_t n = v.n_reads;
+    const uint32_t words = v.guide_words;
+    std::vector<uint32_t> guide((size_t)words * 8);
+    MSQ_HIP(hipMemcpyAsync(guide.data(), v.guide, guide.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> var_cols;
+    for (uint32_t w = 0; w < words; ++w)
+        for (uint32_t m = guide[(size_t)w * 8 + 7]; m; m &= m - 1) var_cols.push_back(w * 32 + (uint32_t)__builtin_ctz(m));
+    constexpr size_t kMaxVar = 4096;
+    if (var_cols.size() > kMaxVar) {  // an even selection: the clustering needs enough columns, not all
+        std::vector<uint32_t> pick;
+        for (size_t i = 0; i < kMaxVar; ++i) pick.push_back(var_cols[i * var_cols.size() / kMaxVar]);
+        var_cols.swap(pick);
+    }
+    const uint32_t nvar = (uint32_t)var_cols.size();
+    if (nvar < 3 || sample < 8) return MSQ_OK;
+    struct Tmp {
+        std::vector<void*> p;
+        ~Tmp()
+        {
+            for (void* q : p)
+                if (q) (void)hipFree(q);
+        }
+        hipError_t alloc(void** out, size_t bytes)
+        {
+            const hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+            if (e == hipSuccess) p.push_back(*out);
+            return e;
+        }
+    } tmp;
+    uint32_t* d_var = nullptr;
+    uint8_t* d_codes = nullptr;
+    MSQ_HIP(tmp.alloc((void**)&d_var, (size_t)nvar * 4));
+    MSQ_HIP(tmp.alloc((void**)&d_codes, (size_t)sample * nvar));
+    MSQ_HIP(hipMemcpyAsync(d_var, var_cols.data(), (size_t)nvar * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(align_sample_codes_kernel, dim3((nvar + 255) / 256, sample), dim3(256), 0, ctx->stream, v.ref_start, v.group_off,
+                       reinterpret_cast<const uint4*>(v.bop), n, origin, sample, d_var, nvar, d_codes);
+    MSQ_HIP(hipGetLastError());
+    std::vector<uint8_t> codes((size_t)sample * nvar);
+    MSQ_HIP(hipMemcpyAsync(codes.data(), d_codes, codes.size(), hipMemcpyDeviceToHost, ctx->stream));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<std::vector<uint8_t>> haps;
+    const int K = cluster_sample(codes, sample, nvar, haps);
+    if (K < 2) return MSQ_OK;
+    // the haplotypes as planes for the assignment: the guide's base everywhere, the group's own at the variant columns
+    std::vector<uint32_t> planes((size_t)K * words * 2), varmask(words, 0);
+    for (int h = 0; h < K; ++h)
+        for (uint32_t w = 0; w < words; ++w) {
+            planes[((size_t)h * words + w) * 2] = guide[(size_t)w * 8 + 1];
+            planes[((size_t)h * words + w) * 2 + 1] = guide[(size_t)w * 8 + 2];
+        }
+    for (uint32_t j = 0; j < nvar; ++j) {
+        const uint32_t w = var_cols[j] >> 5, bit = 1u << (var_cols[j] & 31u);
+        varmask[w] |= bit;
+        for (int h = 0; h < K; ++h) {
+            const uint8_t c = haps[h][j];
+            if (c > 3) continue;
+            uint32_t* p = &planes[((size_t)h * words + w) * 2];
+            p[0] = (p[0] & ~bit) | ((c & 1) ? bit : 0u);
+            p[1] = (p[1] & ~bit) | ((c & 2) ? bit : 0u);
+        }
+    }
+    uint32_t *d_planes = nullptr, *d_mask = nullptr, *d_idx = nullptr, *d_counts = nullptr;
+    uint8_t *d_hap = nullptr, *d_hap_sorted = nullptr;
+    MSQ_HIP(tmp.alloc((void**)&d_planes, planes.size() * 4));
+    MSQ_HIP(tmp.alloc((void**)&d_mask, (size_t)words * 4));
+    MSQ_HIP(tmp.alloc((void**)&d_idx, n * 4));
+    MSQ_HIP(tmp.alloc((void**)&d_counts, MSQ_MAX_HAPS * 4));
+    MSQ_HIP(tmp.alloc((void**)&d_hap, n));
+    MSQ_HIP(tmp.alloc((void**)&d_hap_sorted, n));
+    MSQ_HIP(hipMemcpyAsync(d_planes, planes.data(), planes.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MSQ_HIP(hipMemcpyAsync(d_mask, varmask.data(), (size_t)words * 4, hipMemcpyHostToDevice, ctx->stream));
+    MSQ_HIP(hipMemsetAsync(d_counts, 0, MSQ_MAX_HAPS * 4, ctx->stream));
+    const uint64_t blocks = std::min<uint64_t>((n + 3) / 4, (uint64_t)ctx->n_cu * 16);
+    hipLaunchKernelGGL(align_assign_kernel, dim3((unsigned)std::max<uint64_t>(1, blocks)), dim3(256), 0, ctx->stream, v.ref_start, v.group_off,
+                       reinterpret_cast<const uint4*>(v.bop), n, origin, d_planes, d_mask, words, K, d_hap, d_idx, d_counts);
+    MSQ_HIP(hipGetLastError());
+    // the reads listed group by group (a stable sort by group: ascending inside a group)
+    MSQ_HIP(hipMalloc(&d->ptrs[11], n * 4));
+    size_t sort_bytes = 0;
+    MSQ_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const uint8_t*)d_hap, d_hap_sorted, (const uint32_t*)d_idx, (uint32_t*)d->ptrs[11], (int)n, 0, 3,
+                                               ctx->stream));
+    void* d_sort = nullptr;
+    MSQ_HIP(tmp.alloc(&d_sort, sort_bytes));
+    MSQ_HIP(hipcub::DeviceRadixSort::SortPairs(d_sort, sort_bytes, (const uint8_t*)d_hap, d_hap_sorted, (const uint32_t*)d_idx, (uint32_t*)d->ptrs[11], (int)n, 0, 3,
+                                               ctx->stream));
+    uint32_t counts[MSQ_MAX_HAPS];
+    MSQ_HIP(hipMemcpyAsync(counts, d_counts, sizeof(counts), hipMemcpyDeviceToHost, ctx->stream));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    // every group's own guide + alt, from its own reads
+    MSQ_HIP(hipMalloc(&d->ptrs[10], (size_t)K * words * 32));
+    MSQ_HIP(hipMemsetAsync(d->ptrs[10], 0, (size_t)K * words * 32, ctx->stream));
+    uint64_t lo = 0;
+    for (int h = 0; h < K; ++h) {
+        if (counts[h]) {
+            const uint32_t smp = (uint32_t)std::min<uint64_t>(counts[h], 2048);
+            hipLaunchKernelGGL(align_guide_kernel, dim3(words), dim3(256), 0, ctx->stream, v.ref_start, v.group_off, reinterpret_cast<const uint4*>(v.bop),
+                               (uint64_t)counts[h], origin, smp, std::max<uint32_t>(3, smp / 256), static_cast<uint32_t*>(d->ptrs[10]) + (size_t)h * words * 8,
+                               static_cast<const uint32_t*>(d->ptrs[11]) + lo);
+            MSQ_HIP(hipGetLastError());
+        }
+        lo += counts[h];
+    }
+    if (lo != n) return msq_fail(MSQ_ERR_HIP, "msq_reads_align: the haplotype groups hold %llu of %llu reads", (unsigned long long)lo, (unsigned long long)n);
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    v.hap_count = (uint32_t)K;
+    v.hap_guides = static_cast<const uint32_t*>(d->ptrs[10]);
+    v.hap_perm = static_cast<const uint32_t*>(d->ptrs[11]);
+    for (int h = 0; h < MSQ_MAX_HAPS; ++h) v.hap_reads[h] = h < K ? counts[h] : 0u;
+    return MSQ_OK;
 }
 
 }  // namespace
@@ -300,10 +557,18 @@ extern "C" int msq_reads_align(msq_ctx* ctx, const msq_packed_reads* d_reads, co
         const uint32_t sample = (uint32_t)std::min<uint64_t>(n, 2048);
         const uint32_t alt_min = std::max<uint32_t>(3, sample / 256);
         hipLaunchKernelGGL(align_guide_kernel, dim3(span_words), dim3(256), 0, ctx->stream, v.ref_start, v.group_off, reinterpret_cast<const uint4*>(v.bop), n,
-                           origin, sample, alt_min, static_cast<uint32_t*>(d->ptrs[9]));
+                           origin, sample, alt_min, static_cast<uint32_t*>(d->ptrs[9]), (const uint32_t*)nullptr);
         if ((e = hipGetLastError()) != hipSuccess) return fail(MSQ_ERR_HIP, "guide kernel", e);
         v.guide = static_cast<const uint32_t*>(d->ptrs[9]);
         v.guide_words = span_words;
+        if (n < 0xffffffffull && !ctx->no_haps) {
+            const int rc = align_haplotypes(ctx, d, origin, sample);
+            if (rc != MSQ_OK) {
+                (void)hipStreamSynchronize(ctx->stream);
+                free_dev(d);
+                return rc;
+            }
+        }
     }
     if (int rc = msq_packed_dev_index(ctx, d)) {  // the generic kernels (phasing lookup, the read-space pileup) take it as any set
         (void)hipStreamSynchronize(ctx->stream);

@@ -102,10 +102,14 @@ extern "C" int msq_reads_bake_qv(msq_ctx* ctx, const msq_packed_reads* d_reads, 
     d->view.gcol = nullptr;  // the source's index belongs to the source: this set gets its own (same groups, same columns)
     d->view.guide = nullptr;  // ... and so does its guide; the groups keep their layout (an aligned source stays aligned)
     d->view.guide_words = 0;
+    d->view.hap_count = 0;
+    d->view.hap_guides = nullptr;
+    d->view.hap_perm = nullptr;
+    for (uint32_t& x : d->view.hap_reads) x = 0;
     if (a.np) d->view.flags |= MSQ_READS_QV_BAKED;
     if (int rc = msq_packed_dev_index(ctx, d)) {
         (void)hipStreamSynchronize(ctx->stream);
-        for (int j = 0; j < 10; ++j)
+        for (int j = 0; j < 12; ++j)
             if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
         delete d;
         return rc;

@@ -59,6 +59,7 @@ extern "C" int msq_ctx_create(int device, msq_ctx** out)
         return rc;
     }
     c->no_merge = std::getenv("MSQ_NO_MERGE") != nullptr;
+    c->no_haps = std::getenv("MSQ_NO_HAPS") != nullptr;
     if (const char* v = std::getenv("MSQ_CARRIER_MIN_BATCHES")) c->carrier_min_batches = (int64_t)strtoll(v, nullptr, 10);
     *out = c;
     return MSQ_OK;
@@ -70,6 +71,7 @@ extern "C" int msq_debug_tune(msq_ctx* ctx, int key, long long value)
     switch (key) {
     case MSQ_TUNE_NO_MERGE: ctx->no_merge = value != 0; return MSQ_OK;
     case MSQ_TUNE_CARRIER_MIN_BATCHES: ctx->carrier_min_batches = (int64_t)value; return MSQ_OK;
+    case MSQ_TUNE_NO_HAPS: ctx->no_haps = value != 0; return MSQ_OK;
     default: return msq_fail(MSQ_ERR_ARG, "msq_debug_tune: unknown key %d", key);
     }
 }

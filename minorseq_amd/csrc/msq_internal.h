@@ -58,6 +58,7 @@ struct msq_ctx {
     // with msq_debug_tune: the launchers look here, never at the environment
     bool no_merge = false;
     int64_t carrier_min_batches = -1;  // < 0: the kernel's default
+    bool no_haps = false;              // MSQ_NO_HAPS / MSQ_TUNE_NO_HAPS: msq_reads_align makes no haplotype groups
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when `lds` exceeds what was last set for this kernel on this device
@@ -66,7 +67,8 @@ int msq_ensure_dynamic_lds(int device, const void* kernel, size_t lds);
 // Packed reads resident in HBM and owned by the library: the eight arrays of msq_packed_reads (ref_start, ref_end,
 // group_off, bop, qual, delqv, subqv, insqv; absent planes NULL) and the view over them.
 struct msq_packed_dev {
-    void* ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [8]: the group column index, [9]: the guide
+    // [8]: the group column index, [9]: the guide, [10]: the haplotype groups' guides, [11]: the reads ordered by group
+    void* ptrs[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     msq_packed_reads view = {};
 };
 

@@ -161,7 +161,7 @@ extern "C" int msq_reads_upload(msq_ctx* ctx, const msq_packed_reads* h, msq_pac
         if (e == hipSuccess && bytes[k])
             e = hipMemcpyAsync(d->ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
-            for (int j = 0; j < 10; ++j)
+            for (int j = 0; j < 12; ++j)
                 if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
             delete d;
             return msq_fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "msq_reads_upload: %s",
@@ -180,9 +180,13 @@ extern "C" int msq_reads_upload(msq_ctx* ctx, const msq_packed_reads* h, msq_pac
     d->view.gcol = nullptr;
     d->view.guide = nullptr;  // a host view's guide (if any) is a host pointer: not carried over
     d->view.guide_words = 0;
+    d->view.hap_count = 0;
+    d->view.hap_guides = nullptr;
+    d->view.hap_perm = nullptr;
+    for (uint32_t& x : d->view.hap_reads) x = 0;
     if (int rc = msq_packed_dev_index(ctx, d)) {  // the group column index, derived on the device
         (void)hipStreamSynchronize(ctx->stream);
-        for (int j = 0; j < 10; ++j)
+        for (int j = 0; j < 12; ++j)
             if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
         delete d;
         return rc;
@@ -198,7 +202,7 @@ extern "C" int msq_packed_dev_free(msq_ctx* ctx, msq_packed_dev* p)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    for (int j = 0; j < 10; ++j)
+    for (int j = 0; j < 12; ++j)
         if (p->ptrs[j]) (void)hipFree(p->ptrs[j]);
     delete p;
     return MSQ_OK;
@@ -361,7 +365,7 @@ static uint64_t compact_records(uint8_t* dst, const void* src, int64_t n, const 
 
 static void free_packed_dev(msq_packed_dev* d)
 {
-    for (int j = 0; j < 10; ++j)
+    for (int j = 0; j < 12; ++j)
         if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
     delete d;
 }

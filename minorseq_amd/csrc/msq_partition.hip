@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void slab_gather_kernel(const uint64_t* __rest
 void free_set(msq_packed_dev* d)
 {
     if (!d) return;
-    for (int j = 0; j < 10; ++j)
+    for (int j = 0; j < 12; ++j)
         if (d->ptrs[j]) (void)hipFree(d->ptrs[j]);
     delete d;
 }

@@ -50,7 +50,18 @@ constexpr int kQueueRoom = 128;    // two reads add at most this many entries: d
 constexpr int kQueueDrainAt = 192; // at the end of a batch: drain when at least this many entries wait (three full waves of lanes: a drain ends with vmcnt(0), a bubble in the load pipeline)
 constexpr int kLanesPerPass = 63;  // productive lanes of a wave; lane 63 lends the next word
 
+// Haplotype groups of a launch: group h is counted by the workgroups wg_first[h] .. wg_first[h + 1] - 1, which share the
+// places lo[h] .. hi[h] - 1 of the set's group-ordered read list.
+struct HapPlan {
+    int n;
+    int wg_first[MSQ_MAX_HAPS + 1];
+    uint32_t lo[MSQ_MAX_HAPS], hi[MSQ_MAX_HAPS];
+};
+
 struct RowsArgs {
+    const uint32_t* perm;        // NULL: no groups, the reads in their own order
+    const uint32_t* hap_guides;  // [groups][guide_words][8]
+    HapPlan hp;
     const int32_t* ref_start;
     const int32_t* ref_end;
     const uint64_t* group_off;
@@ -123,14 +134,37 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
+    // ---- haplotype groups: this workgroup counts the reads of ONE group against that group's guide.  Places are read
+    // indices (no groups) or indices into the group-ordered list
+    uint32_t wg_eff = wg, nwg_eff = nwg;
+    uint64_t pos_lo = a.read_lo, pos_hi = a.read_hi;
+    uint32_t n_batches = (uint32_t)a.n_batches;
+    const uint32_t* gsrc = a.guide;
+    if (a.perm) {
+        int hap = 0;
+#pragma unroll
+        for (int h = 1; h < MSQ_MAX_HAPS; ++h)
+            if (h < a.hp.n && wg >= (uint32_t)a.hp.wg_first[h]) hap = h;
+#pragma unroll
+        for (int h = 0; h < MSQ_MAX_HAPS; ++h)
+            if (hap == h) {
+                wg_eff = wg - (uint32_t)a.hp.wg_first[h];
+                nwg_eff = (uint32_t)(a.hp.wg_first[h + 1] - a.hp.wg_first[h]);
+                pos_lo = a.hp.lo[h];
+                pos_hi = a.hp.hi[h];
+            }
+        n_batches = (uint32_t)((pos_hi - pos_lo + kRows - 1) / kRows);
+        gsrc = a.hap_guides + (size_t)hap * a.guide_words * 8;
+    }
+
     // ---- set-up: the guide words of the window from the set's guide (grid word = window word + word0)
     if (tid < 20) draw_ctr[tid] = 0;
     for (int i = tid; i < (G + 2) * 4; i += T) {
         const int w = i >> 2, k = i & 3;
         const long long gw = (long long)a.word0 + a.slab_w0 + w;  // words G, G + 1: the next slab's first words, or nothing
         const bool in = a.slab_w0 + w < a.Gtot && gw >= 0 && gw < (long long)a.guide_words;
-        gl[i] = in ? a.guide[(size_t)gw * 8 + k] : 0u;
-        gl2[i] = in ? a.guide[(size_t)gw * 8 + 4 + k] : 0u;
+        gl[i] = in ? gsrc[(size_t)gw * 8 + k] : 0u;
+        gl2[i] = in ? gsrc[(size_t)gw * 8 + 4 + k] : 0u;
     }
     for (int i = tid; i < 3 * G * 32; i += T) altc[i] = 0;  // alt counters and both substitution tables
     // (msq_pileup_step) this workgroup's share of the shard's reads for the window bounds
@@ -169,7 +203,7 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
         for (int l = 0; l < kLevels; ++l) cnt[k][l] = 0;
 
     // ---- batches are drawn from the role's counter of the workgroup: the t-th draw is batch t * workgroups + this workgroup
-    const uint32_t n_batches = (uint32_t)a.n_batches;
+    // (the workgroups of this workgroup's group)
     uint32_t n_taken = 0;
     auto draw = [&]() -> uint32_t {
         uint32_t t = 0xffffffffu;
@@ -182,26 +216,29 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
 #endif
             n_taken = uni(n_taken + 1u);
         }
-        const uint32_t b = t == 0xffffffffu ? 0xffffffffu : t * nwg + wg;
+        const uint32_t b = t == 0xffffffffu ? 0xffffffffu : t * nwg_eff + wg_eff;
         return b < n_batches ? b : 0xffffffffu;
     };
-    // the table entries of a batch's reads: two vector loads, lane i = read i (lane 8 = the end of read 7); clamped indices
-    // -- a read past the shard's end, and every read of "no batch", has no groups
+    // the table entries of a batch's reads, lane i = read i: which read sits at the lane's place (the place itself, or the
+    // group-ordered list's entry -- fetched a batch before the tables), then its group offsets and start column; clamped
+    // places -- a place past the end, and every place of "no batch", counts as a read without groups
     const uint32_t* const go32 = reinterpret_cast<const uint32_t*>(a.group_off);
     const uint64_t bop_base = (uint64_t)(uintptr_t)a.bop;
-    auto fetch_table = [&](uint32_t b, uint32_t& go_lo, uint32_t& go_hi, int32_t& rs) {
-        const uint64_t r0 = a.read_lo + (uint64_t)(b == 0xffffffffu ? 0u : b) * kRows;
-        const uint64_t r = min(r0 + (uint64_t)min(lane, kRows), a.read_hi);
+    auto fetch_read = [&](uint32_t b) -> uint64_t {
+        const uint64_t p = min(pos_lo + (uint64_t)(b == 0xffffffffu ? 0u : b) * kRows + (uint64_t)min(lane, kRows - 1), pos_hi - 1);
+        return a.perm ? (uint64_t)a.perm[p] : p;
+    };
+    auto fetch_table = [&](uint64_t r, uint32_t& go_lo, uint32_t& go_hi, uint32_t& go_nx, int32_t& rs) {
         go_lo = go32[2 * r];
         go_hi = go32[2 * r + 1];
-        rs = a.ref_start[min(r, a.read_hi - 1)];
+        go_nx = go32[2 * r + 2];
+        rs = a.ref_start[r];
     };
-    auto make_table = [&](uint32_t b, uint32_t go_lo, uint32_t go_hi, int32_t rs) -> RowTable {
+    auto make_table = [&](uint32_t b, uint32_t go_lo, uint32_t go_hi, uint32_t go_nx, int32_t rs) -> RowTable {
         const uint64_t o0 = ((uint64_t)go_hi << 32) | go_lo;
-        const uint32_t next_lo = dpp_next_lane(go_lo);
-        const uint64_t r0 = a.read_lo + (uint64_t)(b == 0xffffffffu ? 0u : b) * kRows;
-        const bool there = b != 0xffffffffu && r0 + (uint64_t)lane < a.read_hi && lane < kRows;
-        const uint32_t ng = there ? next_lo - go_lo : 0u;  // a read spans < 2^32 groups
+        const uint64_t p0 = pos_lo + (uint64_t)(b == 0xffffffffu ? 0u : b) * kRows;
+        const bool there = b != 0xffffffffu && p0 + (uint64_t)lane < pos_hi && lane < kRows;
+        const uint32_t ng = there ? go_nx - go_lo : 0u;  // a read spans < 2^32 groups
         const int32_t rel = ((rs - a.origin) >> 5) - a.word0;  // window word of the read's first group
         const uint64_t base = bop_base + (o0 << 4);
         // a read that reaches outside the window: assert(pos >= 0) / a write past the row (src/MSA.cpp:149)
@@ -366,18 +403,19 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
 
     // ---- the stream: the words of the current batch sit in registers; the registers of four reads are re-loaded
     // with the next batch's words as soon as those four reads are counted; the table of the batch after next is in flight
-    uint32_t b_cur = draw(), b_nxt = draw(), b_nn = draw();
-    uint32_t f_lo, f_hi;
+    uint32_t b_cur = draw(), b_nxt = draw(), b_nn = draw(), b_n3 = draw();
+    uint32_t f_lo, f_hi, f_nx;
     int32_t f_rs;
-    fetch_table(b_cur, f_lo, f_hi, f_rs);
-    RowTable tab = make_table(b_cur, f_lo, f_hi, f_rs);
+    fetch_table(fetch_read(b_cur), f_lo, f_hi, f_nx, f_rs);
+    RowTable tab = make_table(b_cur, f_lo, f_hi, f_nx, f_rs);
     uint4 wd[kRows];
     uint32_t ins[kRows];
 #pragma unroll
     for (int i = 0; i < kRows; ++i) wd[i] = load_word(tab, i, ins[i]);
-    fetch_table(b_nxt, f_lo, f_hi, f_rs);
-    tab = make_table(b_nxt, f_lo, f_hi, f_rs);
-    fetch_table(b_nn, f_lo, f_hi, f_rs);
+    fetch_table(fetch_read(b_nxt), f_lo, f_hi, f_nx, f_rs);
+    tab = make_table(b_nxt, f_lo, f_hi, f_nx, f_rs);
+    fetch_table(fetch_read(b_nn), f_lo, f_hi, f_nx, f_rs);
+    uint64_t r_n3 = fetch_read(b_n3);
     if (with_bounds) {  // wave maxima (order-preserving unsigned codes) meet in LDS, one atomic pair per workgroup goes out
         uint32_t k_lo = ~((uint32_t)b_lo ^ 0x80000000u), k_hi = (uint32_t)b_hi ^ 0x80000000u;
         for (int d = 32; d >= 1; d >>= 1) {
@@ -441,11 +479,13 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
             }
         }
         if (qn >= (uint32_t)kQueueDrainAt) drain();
-        tab = make_table(b_nn, f_lo, f_hi, f_rs);  // the entries fetched a batch ago
+        tab = make_table(b_nn, f_lo, f_hi, f_nx, f_rs);  // the entries fetched a batch ago
         b_cur = b_nxt;
         b_nxt = b_nn;
-        b_nn = draw();
-        fetch_table(b_nn, f_lo, f_hi, f_rs);
+        b_nn = b_n3;
+        fetch_table(r_n3, f_lo, f_hi, f_nx, f_rs);  // of the read looked up a batch ago
+        b_n3 = draw();
+        r_n3 = fetch_read(b_n3);
     }
     if (qn) drain();
 #if MSQ_ROWS_PAIR == 2
@@ -557,6 +597,43 @@ extern "C" int msq_debug_rows_counters(unsigned long long* out8)
     return MSQ_OK;
 }
 
+// The plan of launch j of n_launch over a set with haplotype groups: group h's share of the launch is the j-th of n_launch
+// equal ranges of its places; wr waves per role and workgroup (fewer for small inputs), p batches per workgroup -- the
+// smallest p for which the groups need no more workgroups than the chip has CUs.  false: p exceeds what a workgroup's
+// counters hold (more launches are needed).
+static bool plan_haps(const msq_packed_reads& R, const uint64_t* hap_off, uint64_t j, uint64_t n_launch, int n_cu, int wr_full, HapPlan* plan, int* wr_out)
+{
+    const int K = (int)R.hap_count;
+    uint64_t batches[MSQ_MAX_HAPS], total = 0;
+    plan->n = K;
+    for (int h = 0; h < K; ++h) {
+        const uint64_t n_h = R.hap_reads[h];
+        const uint64_t lo = hap_off[h] + j * n_h / n_launch, hi = hap_off[h] + (j + 1) * n_h / n_launch;
+        plan->lo[h] = (uint32_t)lo;
+        plan->hi[h] = (uint32_t)hi;
+        batches[h] = (hi - lo + kRows - 1) / kRows;
+        total += batches[h];
+    }
+    for (int h = K; h < MSQ_MAX_HAPS; ++h) plan->lo[h] = plan->hi[h] = 0;
+    int wr = wr_full;
+    if ((uint64_t)n_cu * wr > total) wr = (int)std::max<uint64_t>(1, std::min<uint64_t>(wr, (total + n_cu - 1) / n_cu));  // small inputs: thinner workgroups
+    uint64_t p = std::max<uint64_t>((uint64_t)wr, (total + n_cu - 1) / n_cu);
+    for (;; ++p) {
+        uint64_t wgs = 0;
+        for (int h = 0; h < K; ++h) wgs += (batches[h] + p - 1) / p;
+        if (wgs <= (uint64_t)n_cu) break;
+    }
+    *wr_out = wr;
+    if (p > (uint64_t)wr * kMaxBatchesPerWave) return false;
+    int at = 0;
+    for (int h = 0; h < K; ++h) {
+        plan->wg_first[h] = at;
+        at += (int)((batches[h] + p - 1) / p);
+    }
+    for (int h = K; h <= MSQ_MAX_HAPS; ++h) plan->wg_first[h] = at;
+    return at > 0;
+}
+
 // The pileup of an aligned set inside [win_begin0, win_begin0 + W).  *handled = false: not this kernel's case (no guide,
 // a window off the set's word grid, exotic symbols, QV planes a threshold would read) -- the
 // caller takes the read-space kernels, for which an aligned set is a plain-layout set like any other.
@@ -610,56 +687,100 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
     }
     rows_kernel_fn kern = pick_rows_kernel(many_n);
     bool marked = false;
+    // haplotype groups (msq_reads_align): the workgroups are dealt out among the groups in proportion to their reads
+    const bool haps = R.hap_count >= 2 && R.hap_count <= MSQ_MAX_HAPS && R.hap_perm && R.hap_guides && R.n_reads < 0xffffffffull;
+    a.perm = haps ? R.hap_perm : nullptr;
+    a.hap_guides = haps ? R.hap_guides : nullptr;
+    uint64_t hap_off[MSQ_MAX_HAPS + 1] = {0};
+    if (haps) {
+        for (uint32_t h = 0; h < R.hap_count; ++h) hap_off[h + 1] = hap_off[h] + R.hap_reads[h];
+        if (hap_off[R.hap_count] != R.n_reads) return msq_fail(MSQ_ERR_ARG, "msq_pileup: the haplotype groups do not add up to the set's reads");
+    }
+    // one launch + its fold: n_wg workgroups of wr waves per role; the reads lo .. hi (no groups) or the plan's places
+    auto launch = [&](int slab, int G, int n_roles, int wr, int n_wg, uint64_t lo, uint64_t hi, const HapPlan* plan, bool last) -> int {
+        const int w = wr * n_roles;
+        const size_t stream_lds = (size_t)w * kQueueCap * 20 + 80 + (size_t)(G + 2) * 32 + (size_t)G * 128 * 3;
+        const size_t slab_lds = (size_t)NC * wr * kLevels * 256;  // one role's levels in the flush
+        const bool flush_wide = slab_lds * n_roles <= 160 * 1024 - 512;
+        const size_t lds = std::max(stream_lds, flush_wide ? slab_lds * n_roles : slab_lds);
+        if (lds > 160 * 1024 - 512) return msq_fail(MSQ_ERR_ARG, "msq_pileup: no LDS for a %d-word slab", G);
+        a.flush_wide = flush_wide ? 1u : 0u;
+        const size_t need = (size_t)n_wg * (NC + 6) * G * 32 * 4;
+        void* sc = fixed_partials;
+        if (fixed_partials) {
+            if (need > fixed_bytes)
+                return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: %zu bytes of workgroup partials exceed the built-in %zu", need, fixed_bytes);
+        } else {
+            int rc = msq_scratch(ctx, need, &sc);
+            if (rc != MSQ_OK) return rc;
+        }
+        a.partials = static_cast<uint32_t*>(sc);
+        a.read_lo = lo;
+        a.read_hi = hi;
+        a.n_batches = (hi - lo + kRows - 1) / kRows;
+        FoldHaps fh;
+        fh.n = 1;
+        fh.wg_first[0] = 0;
+        fh.wg_first[1] = n_wg;
+        if (plan) {
+            a.hp = *plan;
+            fh.n = plan->n;
+            for (int h = 0; h <= plan->n; ++h) fh.wg_first[h] = plan->wg_first[h];
+        }
+        if (!marked) {
+            msq_timing_mark_begin(ctx);
+            marked = true;
+        }
+        if (int rc = msq_ensure_dynamic_lds(ctx->device, reinterpret_cast<const void*>(kern), lds)) return rc;
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
+        if (last) msq_timing_mark_end(ctx);
+        MSQ_HIP(hipGetLastError());
+        const int col_blocks = (G * 32 + kFoldCols - 1) / kFoldCols;
+        const int slices = d_dev ? 1 : std::max(1, std::min(n_wg / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
+        hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
+                           a.slab_w0 * 32, W, d_nuc, d_codon, d_dev ? a.nuc : (uint32_t*)nullptr, d_dev ? a.codon : (uint32_t*)nullptr, NC + 6, fh);
+        MSQ_HIP(hipGetLastError());
+        (void)slab;
+        return MSQ_OK;
+    };
     for (int slab = 0; slab < n_slabs; ++slab) {
         const int G = std::min(Gslab, Gtot - slab * Gslab);
         const int n_roles = G <= kLanesPerPass ? 1 : 2;
         a.G = G;
         a.slab_w0 = slab * Gslab;
         a.n_roles = n_roles;
+        const int wr_full = kRowsWaves / n_roles;  // waves per role
         // every role sees every batch: a workgroup counts (waves of a role) x 127 batches
-        const uint64_t reads_per_launch = (uint64_t)ctx->n_cu * (kRowsWaves / n_roles) * kMaxBatchesPerWave * kRows;
-        if (d_step_bounds && R.n_reads > reads_per_launch) return MSQ_OK;
+        const uint64_t reads_per_launch = (uint64_t)ctx->n_cu * wr_full * kMaxBatchesPerWave * kRows;
+        if (d_step_bounds && R.n_reads > reads_per_launch) return marked ? msq_fail(MSQ_ERR_ARG, "msq_pileup_step: internal") : MSQ_OK;
+        if (haps) {
+            // launches: every group's reads in `n_launch` equal ranges, one range per launch; a launch's workgroups in
+            // proportion to the ranges: p batches per workgroup, the smallest p that needs no more workgroups than CUs
+            uint64_t n_launch = (R.n_reads + reads_per_launch - 1) / reads_per_launch;
+            HapPlan plan;
+            int wr = wr_full;
+            for (;; ++n_launch) {
+                bool fits = true;
+                for (uint64_t j = 0; j < n_launch && fits; ++j) fits = plan_haps(R, hap_off, j, n_launch, ctx->n_cu, wr_full, &plan, &wr);
+                if (fits) break;
+                if (n_launch > R.n_reads) return msq_fail(MSQ_ERR_ARG, "msq_pileup: no launch plan for the haplotype groups");
+            }
+            if (d_step_bounds && n_launch != 1) return marked ? msq_fail(MSQ_ERR_ARG, "msq_pileup_step: internal") : MSQ_OK;
+            for (uint64_t j = 0; j < n_launch; ++j) {
+                plan_haps(R, hap_off, j, n_launch, ctx->n_cu, wr_full, &plan, &wr);
+                if (int rc = launch(slab, G, n_roles, wr, plan.wg_first[plan.n], 0, R.n_reads, &plan, slab + 1 == n_slabs && j + 1 == n_launch)) return rc;
+            }
+            continue;
+        }
         for (uint64_t lo = 0; lo < R.n_reads; lo += reads_per_launch) {
             const uint64_t hi = std::min<uint64_t>(R.n_reads, lo + reads_per_launch);
             const uint64_t n_batches = (hi - lo + kRows - 1) / kRows;
-            int wr = kRowsWaves / n_roles, n_wg = ctx->n_cu;  // waves per role
+            int wr = wr_full, n_wg = ctx->n_cu;
             if ((uint64_t)n_wg * wr > n_batches) {  // small inputs: fewer, thinner workgroups
                 wr = (int)std::max<uint64_t>(1, std::min<uint64_t>(wr, (n_batches + ctx->n_cu - 1) / ctx->n_cu));
                 n_wg = (int)((n_batches + wr - 1) / wr);
             }
-            const int w = wr * n_roles;
-            const size_t stream_lds = (size_t)w * kQueueCap * 20 + 80 + (size_t)(G + 2) * 32 + (size_t)G * 128 * 3;
-            const size_t slab_lds = (size_t)NC * wr * kLevels * 256;  // one role's levels in the flush
-            const bool flush_wide = slab_lds * n_roles <= 160 * 1024 - 512;
-            const size_t lds = std::max(stream_lds, flush_wide ? slab_lds * n_roles : slab_lds);
-            if (lds > 160 * 1024 - 512) return marked ? msq_fail(MSQ_ERR_ARG, "msq_pileup: no LDS for a %d-word slab", G) : MSQ_OK;
-            a.flush_wide = flush_wide ? 1u : 0u;
-            const size_t need = (size_t)n_wg * (NC + 6) * G * 32 * 4;
-            void* s = fixed_partials;
-            if (fixed_partials) {
-                if (need > fixed_bytes)
-                    return msq_fail(MSQ_ERR_ARG, "msq_pileup_noalloc: %zu bytes of workgroup partials exceed the built-in %zu", need, fixed_bytes);
-            } else {
-                int rc = msq_scratch(ctx, need, &s);
-                if (rc != MSQ_OK) return rc;
-            }
-            a.partials = static_cast<uint32_t*>(s);
-            a.read_lo = lo;
-            a.read_hi = hi;
-            a.n_batches = n_batches;
-            if (!marked) {
-                msq_timing_mark_begin(ctx);
-                marked = true;
-            }
-            if (int rc = msq_ensure_dynamic_lds(ctx->device, reinterpret_cast<const void*>(kern), lds)) return rc;
-            hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
-            if (slab + 1 == n_slabs && hi == R.n_reads) msq_timing_mark_end(ctx);
-            MSQ_HIP(hipGetLastError());
-            const int col_blocks = (G * 32 + kFoldCols - 1) / kFoldCols;
-            const int slices = d_dev ? 1 : std::max(1, std::min(n_wg / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
-            hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
-                               a.slab_w0 * 32, W, d_nuc, d_codon, d_dev ? a.nuc : (uint32_t*)nullptr, d_dev ? a.codon : (uint32_t*)nullptr, NC + 6);
-            MSQ_HIP(hipGetLastError());
+            if (int rc = launch(slab, G, n_roles, wr, n_wg, lo, hi, nullptr, slab + 1 == n_slabs && hi == R.n_reads)) return rc;
         }
     }
     *handled = true;

@@ -133,18 +133,40 @@ __device__ __forceinline__ uint32_t codon_cols_of(int cg, int W)  // cg: word of
 // atomic per bin.  blockIdx.y slices the workgroups further (more blocks, but as many more global atomics).
 constexpr int kFoldCols = 32, kFoldSubs = 32, kFoldTrip = 8;
 // rows: partial rows per workgroup -- NC + 4, or NC + 6 when the kernel also hands over its tables of isolated
-// substitutions (msq_pileup_rows.hip; every workgroup of such a launch counts against the same guide).
+// substitutions (msq_pileup_rows.hip).  Those tables count by rank relative to the workgroup's guide, so they are summed
+// per haplotype group (FoldHaps: the workgroups wg_first[h] .. wg_first[h + 1] - 1 share a guide) and expanded with that
+// group's guide.
+struct FoldHaps {
+    int n;
+    int wg_first[9];
+};
 __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols, int col0, int W,
                                               uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
-                                              uint32_t* __restrict__ dev_codon, int rows)
+                                              uint32_t* __restrict__ dev_codon, int rows, const FoldHaps& fh)
 {
     constexpr int kCodStride = 65, kNucStride = 7;  // odd strides: the lanes of a wave are columns
     __shared__ uint32_t cod_acc[kFoldCols * kCodStride];
     __shared__ uint32_t nuc_acc[kFoldCols * kNucStride];
-    __shared__ uint32_t sub_acc[(kFoldCols + 2) * 3];  // isolated substitutions of the block's columns and the next two, by rank
+    constexpr int kSubStride = (kFoldCols + 2) * 3;
+    __shared__ uint32_t sub_acc[8 * kSubStride];  // per haplotype group: isolated substitutions of the block's columns and the next two, by rank
     const bool with_subs = rows > NC + 4;
     const int T = kFoldCols * kFoldSubs, tid = threadIdx.x;
-    for (int i = tid; i < (kFoldCols + 2) * 3; i += T) sub_acc[i] = 0;
+    __shared__ int wgf[9];  // fh.wg_first where a thread indexes it by its own number
+    for (int i = tid; i < 8 * kSubStride; i += T) sub_acc[i] = 0;
+    if (tid < 9) {
+        int v = fh.wg_first[8];
+#pragma unroll
+        for (int k = 7; k >= 0; --k)
+            if (tid == k) v = fh.wg_first[k];
+        wgf[tid] = tid <= fh.n ? v : fh.wg_first[0];
+    }
+    auto hap_of = [&](int wg) -> int {
+        int h = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+            if (k < fh.n && wg >= fh.wg_first[k]) h = k;
+        return h;
+    };
     for (int i = tid; i < kFoldCols * kCodStride; i += T) cod_acc[i] = 0;
     for (int i = tid; i < kFoldCols * kNucStride; i += T) nuc_acc[i] = 0;
     const int cl = tid & (kFoldCols - 1), sub = tid / kFoldCols;
@@ -152,8 +174,11 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
     const int per = (n_wg + gridDim.y - 1) / gridDim.y;
     const int wg_lo = blockIdx.y * per, wg_hi = min(n_wg, wg_lo + per);
     const bool valid = c < cols && col0 + c < W;
-    uint32_t meta_first = 0;  // the guide's bins of this column as the first workgroup wrote them
     __syncthreads();
+    // thread `sub` of a column expands group `sub`'s substitution tables at the end: the group's guide at this column, as
+    // the group's first workgroup wrote it, is fetched now
+    const bool expands = with_subs && valid && sub < fh.n && wgf[min(sub, 7) + 1] > wgf[min(sub, 7)];
+    const uint32_t meta_of_group = expands ? partials[(size_t)wgf[min(sub, 7)] * rows * cols + (size_t)NC * cols + c] : 0u;
     if (valid) {
         uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0;
         // codon counts: runs of workgroups that agree on the bin are added up before they cost an atomic (set 0 = the
@@ -162,8 +187,17 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
         int cod_idx[2] = {-1, -1};
         // isolated substitutions (rows NC + 4, NC + 5) of this column, unpacked and summed; the codons one changes start
         // up to two columns before it: the threads of columns 0 and 1 also sum the next block's columns 0 and 1
-        uint32_t sr[3] = {0, 0, 0}, sr2[3] = {0, 0, 0};
+        uint32_t sr[3] = {0, 0, 0};
+        int sr_hap = -1;  // runs of workgroups of one group are added up before they go to LDS
         const bool margin = with_subs && cl < 2 && c + kFoldCols < cols;
+        auto flush_subs = [&](int at) {
+            if (sr_hap >= 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    if (sr[r]) atomicAdd(&sub_acc[sr_hap * kSubStride + at * 3 + r], sr[r]);
+            }
+            sr[0] = sr[1] = sr[2] = 0;
+        };
         auto add_codon = [&](int set, uint32_t meta, uint32_t n) {
             if (!n) return;
             const int idx = (int)((meta >> 8) & 63u);
@@ -192,7 +226,6 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
                 acm[u] = p[(size_t)(NC + 2) * cols + c];
                 meta2[u] = p[(size_t)(NC + 3) * cols + c];
             }
-            if (wg0 == wg_lo + sub) meta_first = meta[0];
 #pragma unroll
             for (int u = 0; u < kFoldTrip; ++u) {
                 if (wg0 + kFoldSubs * u >= wg_hi) break;
@@ -203,11 +236,20 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
                 nn += n4[u];
                 add_codon(0, meta[u], cm[u]);
                 add_codon(1, meta2[u], acm[u]);
-                sr[0] += sa[u] & 0xffffu;
-                sr[1] += sa[u] >> 16;
-                sr[2] += sb[u];
+                if (with_subs) {
+                    const int h = fh.n > 1 ? hap_of(wg0 + kFoldSubs * u) : 0;
+                    if (h != sr_hap) {
+                        flush_subs(cl);
+                        sr_hap = h;
+                    }
+                    sr[0] += sa[u] & 0xffffu;
+                    sr[1] += sa[u] >> 16;
+                    sr[2] += sb[u];
+                }
             }
         }
+        flush_subs(cl);
+        sr_hap = -1;
         if (margin) {  // a trip of its own (two lanes of 32): kept out of the main trip, whose registers are full
             for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += kFoldSubs * kFoldTrip) {
                 uint32_t sa[kFoldTrip], sb[kFoldTrip];
@@ -221,16 +263,18 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
                 }
 #pragma unroll
                 for (int u = 0; u < kFoldTrip; ++u) {
-                    sr2[0] += sa[u] & 0xffffu;
-                    sr2[1] += sa[u] >> 16;
-                    sr2[2] += sb[u];
+                    if (wg0 + kFoldSubs * u >= wg_hi) break;
+                    const int h = fh.n > 1 ? hap_of(wg0 + kFoldSubs * u) : 0;
+                    if (h != sr_hap) {
+                        flush_subs(kFoldCols + cl);
+                        sr_hap = h;
+                    }
+                    sr[0] += sa[u] & 0xffffu;
+                    sr[1] += sa[u] >> 16;
+                    sr[2] += sb[u];
                 }
             }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            if (sr[r]) atomicAdd(&sub_acc[cl * 3 + r], sr[r]);
-            if (sr2[r]) atomicAdd(&sub_acc[(kFoldCols + cl) * 3 + r], sr2[r]);
+            flush_subs(kFoldCols + cl);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -243,13 +287,14 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
     }
     if (with_subs) {
         __syncthreads();
-        if (sub == 0 && valid) {
-            const uint32_t meta = meta_first;  // every workgroup of such a launch counts against the same guide
+        if (expands) {
+            const uint32_t meta = meta_of_group;
+            const uint32_t* const sa = sub_acc + sub * kSubStride;
             const uint32_t k0 = meta & 3u, cidx = (meta >> 8) & 63u;
             const int wc = col0 + c;  // window column
 #pragma unroll
             for (int r = 0; r < 3; ++r)  // MSAColumn::IncCounts: the base read at this column
-                if (const uint32_t n = sub_acc[cl * 3 + r]) atomicAdd(&nuc_acc[cl * kNucStride + ((k0 + 1u + (uint32_t)r) & 3u)], n);
+                if (const uint32_t n = sa[cl * 3 + r]) atomicAdd(&nuc_acc[cl * kNucStride + ((k0 + 1u + (uint32_t)r) & 3u)], n);
             if (wc >= 1 && wc <= W - 3) {  // a column that can start a codon (MSARow::CodonAt's i > 0, CodingCodonAt's bound)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {  // the substitution sits in position q of the codon that starts here
@@ -257,7 +302,7 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
                     const uint32_t kq = (cidx >> shift) & 3u;
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
-                        if (const uint32_t n = sub_acc[(cl + q) * 3 + r])
+                        if (const uint32_t n = sa[(cl + q) * 3 + r])
                             atomicAdd(&cod_acc[cl * kCodStride + ((cidx & ~(3u << shift)) | (((kq + 1u + (uint32_t)r) & 3u) << shift))], n);
                 }
             }
@@ -296,9 +341,9 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
 __attribute__((unused)) __global__ __launch_bounds__(kFoldCols* kFoldSubs) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
                                                                              int col0, int W, uint32_t* __restrict__ nuc,
                                                                              uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
-                                                                             uint32_t* __restrict__ dev_codon, int rows)
+                                                                             uint32_t* __restrict__ dev_codon, int rows, FoldHaps fh)
 {
-    fold_partials(partials, n_wg, NC, cols, col0, W, nuc, codon, dev_nuc, dev_codon, rows);
+    fold_partials(partials, n_wg, NC, cols, col0, W, nuc, codon, dev_nuc, dev_codon, rows, fh);
 }
 
 // the folds of a merged launch as one launch: blockIdx.z = the slab
@@ -311,7 +356,11 @@ __attribute__((unused)) __global__ __launch_bounds__(kFoldCols* kFoldSubs) void 
 {
     const int sl = blockIdx.z;
     if ((int)blockIdx.x * kFoldCols >= t.cols[sl]) return;  // the grid is as wide as the widest slab
-    fold_partials(t.partials[sl], t.n_wg[sl], NC, t.cols[sl], t.col0[sl], W, nuc, codon, nullptr, nullptr, NC + 4);
+    FoldHaps fh;
+    fh.n = 1;
+    fh.wg_first[0] = 0;
+    fh.wg_first[1] = t.n_wg[sl];
+    fold_partials(t.partials[sl], t.n_wg[sl], NC, t.cols[sl], t.col0[sl], W, nuc, codon, nullptr, nullptr, NC + 4, fh);
 }
 
 

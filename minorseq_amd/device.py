@@ -184,7 +184,10 @@ class LibReads:
                 "group_off": back(v.group_off, np.uint64, n + 1), "bop": back(v.bop, np.uint32, g * 4),
                 "qual": back(v.qual, np.uint8, g * 32), "delqv": back(v.delqv, np.uint8, g * 32),
                 "subqv": back(v.subqv, np.uint8, g * 32), "insqv": back(v.insqv, np.uint8, g * 32), "flags": self.flags,
-                "align_origin": int(v.align_origin), "guide": back(v.guide, np.uint32, int(v.guide_words) * 8)}
+                "align_origin": int(v.align_origin), "guide": back(v.guide, np.uint32, int(v.guide_words) * 8),
+                "hap_count": int(v.hap_count), "hap_reads": [int(x) for x in v.hap_reads],
+                "hap_guides": back(v.hap_guides, np.uint32, int(v.hap_count) * int(v.guide_words) * 8),
+                "hap_perm": back(v.hap_perm, np.uint32, n if v.hap_perm else 0)}
 
     def close(self):
         if self.handle is not None:

@@ -270,3 +270,80 @@ def test_noalloc_on_an_aligned_set_too_wide_for_its_built_in_partials(ctx):
     assert L.msq_debug_ctx_device_bytes(ctx.h) == held and torch.cuda.mem_get_info()[0] == free
     assert torch.equal(nuc, want[0]) and torch.equal(codon, want[1])
     al.close()
+
+
+@pytest.mark.parametrize("kw,min_groups", [
+    (dict(n_minors=2, minor_frac=0.03, minor_codons=300), 3),   # two clones whose variant codons overlap and touch
+    (dict(n_minors=4, minor_frac=0.2, minor_codons=100), 5),    # five strains at 20 % each
+    (dict(n_minors=4, minor_frac=0.01, minor_codons=100), 2),   # small clones: some may stay below the sample's support
+    (dict(n_minors=7, minor_frac=0.1, minor_codons=30), 8),     # as many groups as the set holds
+])
+def test_haplotype_groups(ctx, kw, min_groups):
+    """Samples of several clones: msq_reads_align groups the reads by haplotype (every read in exactly one group, the list
+    ascending inside a group, a guide per group that is the group's own majority), the kernel counts every group against
+    its own guide -- same matrices as the simple kernel, through msq_pileup, the fused step and with the grouping
+    switched off."""
+    n = 60000
+    wl = synth.workload("pol_100k", n_reads=n, **kw)
+    src = device.synth_device(ctx, wl, 0, n)
+    W, b0 = wl.W, wl.win_begin0
+    al = device.align(ctx, src, NONE, b0)
+    got = al.download()
+    K = got["hap_count"]
+    assert min_groups <= K <= 8
+    sizes = got["hap_reads"][:K]
+    assert sum(sizes) == n and not any(got["hap_reads"][K:])
+    perm = got["hap_perm"]
+    assert np.array_equal(np.sort(perm), np.arange(n, dtype=np.uint32))
+    lo = 0
+    for h in range(K):
+        part = perm[lo:lo + sizes[h]]
+        assert (np.diff(part.astype(np.int64)) > 0).all()
+        lo += sizes[h]
+    assert sizes[0] >= 0.9 * max(sizes)  # ordered by their size in the SAMPLE
+    want = device.pileup(ctx, src, NONE, b0, W, mode=abi.MSQ_PILEUP_SIMPLE)
+    res = device.pileup(ctx, al, NONE, b0, W, mode=abi.MSQ_PILEUP_ROWS)
+    assert torch.equal(res[0], want[0]) and torch.equal(res[1], want[1])
+    buf = torch.full((W * 70,), 777, dtype=torch.int32, device="cuda")
+    bounds = torch.zeros(2, dtype=torch.int32, device="cuda")
+    L = abi.lib()
+    abi.check(L.msq_pileup_step(ctx.h, al.view, NONE, b0, W, bounds.data_ptr(), buf.data_ptr()))
+    abi.check(L.msq_pileup_check(ctx.h))
+    assert bounds.tolist() == [-b0, b0 + W] and torch.equal(buf[:W * 6], want[0]) and torch.equal(buf[W * 6:], want[1])
+    # a group's guide is the majority of the group's own reads: group 0 of the five strains differs from the set's guide
+    # nowhere but at variant columns, and every group's guide covers the window
+    g = got["hap_guides"].reshape(K, -1, 8)
+    assert (g[:, :W // 32, 0] == 0xffffffff).all()
+    # grouping switched off: one population, same counts
+    abi.check(L.msq_debug_tune(ctx.h, 3, 1))
+    try:
+        flat = device.align(ctx, src, NONE, b0)
+    finally:
+        abi.check(L.msq_debug_tune(ctx.h, 3, 0))
+    assert flat.download()["hap_count"] == 0
+    res = device.pileup(ctx, flat, NONE, b0, W, mode=abi.MSQ_PILEUP_ROWS)
+    assert torch.equal(res[0], want[0]) and torch.equal(res[1], want[1])
+    flat.close()
+    al.close()
+
+
+def test_haplotype_groups_over_several_launches_and_slabs(ctx):
+    """2.2 million reads of three clones take two launches (each group's reads in two ranges); a wide window goes slab by
+    slab with the same groups."""
+    wl = synth.workload("pol_100k", n_reads=2200000, n_minors=2, minor_frac=0.2, minor_codons=60)
+    src = device.synth_device(ctx, wl, 0, wl.n_reads)
+    al = device.align(ctx, src, NONE, wl.win_begin0)
+    assert al.download()["hap_count"] == 3
+    want = device.pileup(ctx, src, NONE, wl.win_begin0, wl.W, mode=abi.MSQ_PILEUP_STREAM)
+    got = device.pileup(ctx, al, NONE, wl.win_begin0, wl.W, mode=abi.MSQ_PILEUP_ROWS)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    al.close()
+    del src
+    wl = synth.workload("hiv_mix_200k", n_reads=30000, n_minors=3, minor_frac=0.15, minor_codons=200)
+    src = device.synth_device(ctx, wl, 0, wl.n_reads)
+    al = device.align(ctx, src, NONE, wl.win_begin0)
+    assert al.download()["hap_count"] >= 2
+    want = device.pileup(ctx, src, NONE, wl.win_begin0, wl.W, mode=abi.MSQ_PILEUP_SIMPLE)
+    got = device.pileup(ctx, al, NONE, wl.win_begin0, wl.W, mode=abi.MSQ_PILEUP_ROWS)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    al.close()
