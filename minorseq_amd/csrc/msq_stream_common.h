@@ -131,7 +131,10 @@ __device__ __forceinline__ uint32_t codon_cols_of(int cg, int W)  // cg: word of
 // lanes: a thread has the loads of eight workgroups' partials in flight at once (the kernel is latency-bound: one
 // trip for 256 workgroups), the 32 lanes of a column meet in LDS, and what is not zero there leaves as one global
 // atomic per bin.  blockIdx.y slices the workgroups further (more blocks, but as many more global atomics).
-constexpr int kFoldCols = 32, kFoldSubs = 32, kFoldTrip = 8;
+#ifndef MSQ_FOLD_COLS
+#define MSQ_FOLD_COLS 32
+#endif
+constexpr int kFoldCols = MSQ_FOLD_COLS, kFoldSubs = 1024 / kFoldCols, kFoldTrip = 256 / kFoldSubs;
 // rows: partial rows per workgroup -- NC + 4, or NC + 6 when the kernel also hands over its tables of isolated
 // substitutions (msq_pileup_rows.hip).  Those tables count by rank relative to the workgroup's guide, so they are summed
 // per haplotype group (FoldHaps: the workgroups wg_first[h] .. wg_first[h + 1] - 1 share a guide) and expanded with that
