@@ -13,10 +13,13 @@
 //    8 x PASSES KB in flight per wave at all times.
 //  * cells that match the set's GUIDE (per column the majority base, learnt when the set was made) are counted in
 //    bit-sliced carry-save counters in registers; a word with anything else goes -- planes and all, 20 bytes -- on a
-//    per-wave LDS queue that is drained one lane per entry when 64 entries are waiting: what matches the set's alt
-//    haplotype is counted in LDS, the rest pays global atomics.  Any guide gives the same counts.
-//  * flush and fold are the stream kernel's (msq_stream_common.h): bit-sliced sums across the waves, one partial per
-//    workgroup, fold_partials_kernel.
+//    per-wave LDS queue that is drained one lane per entry when 192 entries are waiting: what matches the set's alt
+//    haplotype is counted in LDS, so are isolated substitutions (by column and rank; the fold expands them), the rest
+//    pays global atomics.  Any guide gives the same counts.
+//  * sets whose reads msq_reads_align grouped by haplotype: a workgroup counts ONE group, through the set's
+//    group-ordered read list, against that group's guide.
+//  * flush: the waves' bit-sliced counters are summed while still bit-sliced, transposed, and leave as ONE partial per
+//    workgroup -- u16s, two columns to a u32; fold_rows_kernel adds the partials into the count matrices.
 //
 // Algorithmic bytes per unit: 0.5 B per column-consuming base + 20 B per read of tables; HBM-bound.
 #include "msq_internal.h"
@@ -79,7 +82,7 @@ struct RowsArgs {
     uint32_t flush_wide;
     uint32_t* nuc;    // where deviations go (the caller's matrices, or the context's deviation matrix in a fused step)
     uint32_t* codon;
-    uint32_t* partials;  // [workgroups][NC + 6][G * 32]
+    uint32_t* partials;  // [workgroups][NC + 5][G * 16]: u16 pairs, columns r and r + 16 of a word share a u32
     uint32_t* err;
     uint32_t* bounds_acc;  // msq_pileup_step: the shard's bounds come out of this launch too (NULL otherwise)
     int32_t* bounds_out;
@@ -511,22 +514,19 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
             a.bounds_out[1] = end0 > 0 ? end0 : 0;
         }
     }
-    const int cols = G * 32;
-    uint32_t* const part = a.partials + (size_t)wg * (NC + 6) * cols;
-    auto meta_of = [&](const uint32_t* g, int c) -> uint32_t {
-        auto bit = [&](int plane, int cc) -> uint32_t { return (g[(cc >> 5) * 4 + plane] >> (cc & 31)) & 1u; };
-        const uint32_t v0 = bit(0, c), v1 = bit(0, c + 1), v2 = bit(0, c + 2);
-        const uint32_t k0 = bit(1, c) | (bit(2, c) << 1), k1 = bit(1, c + 1) | (bit(2, c + 1) << 1), k2 = bit(1, c + 2) | (bit(2, c + 2) << 1);
-        return k0 | (v0 << 2) | (((k0 << 4) | (k1 << 2) | k2) << 8) | ((v0 & v1 & v2) << 14);
-    };
-    for (int c = tid; c < cols; c += T) {
-        part[(size_t)NC * cols + c] = meta_of(gl, c);
-        const uint32_t ac = altc[c];
-        part[(size_t)(NC + 1) * cols + c] = ac & 0xffffu;
-        part[(size_t)(NC + 2) * cols + c] = ac >> 16;
-        part[(size_t)(NC + 3) * cols + c] = meta_of(gl2, c);
-        part[(size_t)(NC + 4) * cols + c] = subA[c];
-        part[(size_t)(NC + 5) * cols + c] = subB[c];
+    // no workgroup counts 65 536 reads, so a partial holds u16s, two to a u32: columns r and r + 16 of a 32-column word --
+    // the way the transposed counters come out.  Rows: the NC counters, the alt nucleotide and codon counts, the three
+    // ranks of the isolated substitutions; the fold works the guides' bins out from the guides themselves
+    const int words16 = G * 16;
+    uint32_t* const part = a.partials + (size_t)wg * (NC + 5) * words16;
+    for (int i = tid; i < words16; i += T) {
+        const int c0 = (i >> 4) * 32 + (i & 15), c1 = c0 + 16;
+        const uint32_t a0 = altc[c0], a1 = altc[c1], s0 = subA[c0], s1 = subA[c1];
+        part[(size_t)(NC + 0) * words16 + i] = (a0 & 0xffffu) | (a1 << 16);
+        part[(size_t)(NC + 1) * words16 + i] = (a0 >> 16) | (a1 & 0xffff0000u);
+        part[(size_t)(NC + 2) * words16 + i] = (s0 & 0xffffu) | (s1 << 16);
+        part[(size_t)(NC + 3) * words16 + i] = (s0 >> 16) | (s1 & 0xffff0000u);
+        part[(size_t)(NC + 4) * words16 + i] = (subB[c0] & 0xffffu) | (subB[c1] << 16);
     }
     constexpr int SL = kLevels + 4;  // levels of a sum over <= 16 waves
     uint32_t* const slab = lds;      // [roles of the round][NC][waves of a role][kLevels][64]: queues and guide are dead
@@ -558,12 +558,9 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
 #pragma unroll
                 for (int l = 0; l < 16; ++l) t16[l] = l < SL ? sum[l] : 0u;
                 transpose16x2(t16);
-                uint4* dst = reinterpret_cast<uint4*>(part + (size_t)k * cols + cgj * 32);
+                uint4* dst = reinterpret_cast<uint4*>(part + (size_t)k * words16 + cgj * 16);  // t16[r] = column r | column r + 16 << 16
 #pragma unroll
-                for (int r = 0; r < 16; r += 4) {
-                    dst[r >> 2] = make_uint4(t16[r] & 0xffffu, t16[r + 1] & 0xffffu, t16[r + 2] & 0xffffu, t16[r + 3] & 0xffffu);
-                    dst[4 + (r >> 2)] = make_uint4(t16[r] >> 16, t16[r + 1] >> 16, t16[r + 2] >> 16, t16[r + 3] >> 16);
-                }
+                for (int r = 0; r < 16; r += 4) dst[r >> 2] = make_uint4(t16[r], t16[r + 1], t16[r + 2], t16[r + 3]);
             }
         }
     };
@@ -577,6 +574,218 @@ __global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a
     for (int i = 0; i < 8; ++i)
         if (dbg[i]) atomicAdd(&rows_dbg[i], dbg[i]);
 #endif
+}
+
+// ---- the fold of the aligned-set kernel's partials into the count matrices (MSAColumn's counts, src/MSA.cpp:68-87; the
+// codon map of CodonsAt, :126-136).  Block = one 32-column word x 32 "subs": thread (column, sub) adds up the u16s of
+// the workgroups sub, sub + 32, ... -- runs of workgroups of one haplotype group in registers, then per (group, column)
+// in LDS -- and thread (column, sub = group) turns the group's sums into bins with the group's guide: matches to the
+// guide's nucleotide / codon bin, gaps to '-', Ns to 'N' (bins 4 and 5, NucleotideConversion.h:69-88), alt counts to the
+// alt's bins, an isolated substitution of rank r at column c to nucleotide (guide + 1 + r) & 3 and to the three codons
+// that hold it.  blockIdx.y slices the workgroups (more blocks; the bins then leave as global atomics).
+struct FoldRowsArgs {
+    const uint32_t* partials;
+    const uint32_t* guides;  // group h's guide at guides + h * guide_words * 8 (no groups: the set's guide)
+    uint32_t guide_words;
+    int n_wg, NC, G, slab_w0, Gtot, word0, W;
+    int n_haps;
+    int wg_first[MSQ_MAX_HAPS + 1];
+    uint32_t *nuc, *codon, *dev_nuc, *dev_codon;
+};
+constexpr int kFoldRowsSubs = 64, kFoldRowsTrip = 4;  // 16 lanes (a u32 = columns r and r + 16) x 64 subs; 4 workgroups per thread and trip
+
+__global__ __launch_bounds__(1024) void fold_rows_kernel(FoldRowsArgs f)
+{
+    constexpr int kCodStride = 65, kNucStride = 7, kQ = 9;  // per (group, column): m, gap, cm, n, alt nuc, alt codon, r0, r1, r2
+    __shared__ uint32_t cod_acc[32 * kCodStride];
+    __shared__ uint32_t nuc_acc[32 * kNucStride];
+    __shared__ uint32_t gacc[MSQ_MAX_HAPS * 34 * kQ];  // columns 32, 33: the next word's first two (substitution ranks only)
+    __shared__ uint32_t gmeta[MSQ_MAX_HAPS * 32], gmeta2[MSQ_MAX_HAPS * 32];
+    __shared__ int wgf[MSQ_MAX_HAPS + 1];
+    const int T = 1024, tid = threadIdx.x, r = tid & 15, sub = tid >> 4, NC = f.NC, G = f.G;
+    const int w = blockIdx.x;              // word of the slab
+    const int cb = (f.slab_w0 + w) * 32;   // window column of the block's column 0
+    const int ncol = min(32, f.W - cb);    // columns of this word inside the window
+    const int per = (f.n_wg + gridDim.y - 1) / gridDim.y;
+    const int wg_lo = blockIdx.y * per, wg_hi = min(f.n_wg, wg_lo + per);
+    const size_t row_words = (size_t)G * 16, wg_words = (size_t)(NC + 5) * row_words;
+    // ---- every global load of the kernel is issued here, in one go: what the deviation path left in its matrix
+    // (msq_pileup_step), the guides' words, the first trip over the partials and the next word's first columns
+    uint32_t dev_c0 = 0, dev_c1 = 0, dev_n = 0;
+    if (f.dev_nuc) {
+        if (tid < ncol * 64) dev_c0 = f.dev_codon[(size_t)cb * 64 + tid];
+        if (tid + T < ncol * 64) dev_c1 = f.dev_codon[(size_t)cb * 64 + tid + T];
+        if (tid < ncol * 6) dev_n = f.dev_nuc[(size_t)cb * 6 + tid];
+    }
+    uint32_t g0[8], g1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g0[k] = g1[k] = 0;
+    if (tid < MSQ_MAX_HAPS * 32 && (tid >> 5) < f.n_haps) {
+        const uint32_t* g = f.guides + (size_t)(tid >> 5) * f.guide_words * 8;
+        const long long gw = (long long)f.word0 + f.slab_w0 + w;
+        if (f.slab_w0 + w < f.Gtot && gw >= 0 && gw < (long long)f.guide_words)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g0[k] = g[(size_t)gw * 8 + k];
+        if (f.slab_w0 + w + 1 < f.Gtot && gw + 1 >= 0 && gw + 1 < (long long)f.guide_words)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g1[k] = g[(size_t)(gw + 1) * 8 + k];
+    }
+    const bool margin = r < 2 && w + 1 < G;
+    const uint32_t* const pcol = f.partials + (size_t)w * 16 + r;
+    uint32_t v[kFoldRowsTrip][kQ], vm[kFoldRowsTrip][3];
+    auto load_trip = [&](int wg0) {
+#pragma unroll
+        for (int u = 0; u < kFoldRowsTrip; ++u) {
+            const int wg = min(wg0 + kFoldRowsSubs * u, wg_hi - 1);  // clamped: a slot past the end is loaded and ignored
+            const uint32_t* p = pcol + (size_t)wg * wg_words;
+            v[u][0] = p[0];
+            v[u][1] = p[row_words];
+            v[u][2] = p[2 * row_words];
+            v[u][3] = NC > 3 ? p[3 * row_words] : 0u;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) v[u][4 + q] = p[(size_t)(NC + q) * row_words];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) vm[u][q] = margin ? p[(size_t)(NC + 2 + q) * row_words + 16] : 0u;  // word w + 1, columns 0 / 1
+        }
+    };
+    const bool any = wg_lo + sub < wg_hi;
+    if (any) load_trip(wg_lo + sub);
+    // ---- LDS: cleared; the groups' first workgroups; the bins of group h's guide (and alt) at every column of this word
+    // (the kernel's meta_of over the same guide words)
+    for (int i = tid; i < 32 * kCodStride; i += T) cod_acc[i] = 0;
+    for (int i = tid; i < 32 * kNucStride; i += T) nuc_acc[i] = 0;
+    for (int i = tid; i < MSQ_MAX_HAPS * 34 * kQ; i += T) gacc[i] = 0;
+    if (tid <= MSQ_MAX_HAPS) {
+        int x = f.wg_first[MSQ_MAX_HAPS];
+#pragma unroll
+        for (int k = MSQ_MAX_HAPS - 1; k >= 0; --k)
+            if (tid == k) x = f.wg_first[k];
+        wgf[tid] = x;
+    }
+    if (tid < MSQ_MAX_HAPS * 32) {
+        const int cl = tid & 31;
+        auto meta_of = [&](int o) -> uint32_t {  // o = 0: the guide's planes, 4: the alt's
+            auto bit = [&](int plane, int cc) -> uint32_t { return cc < 32 ? (g0[o + plane] >> cc) & 1u : (g1[o + plane] >> (cc - 32)) & 1u; };
+            const uint32_t v0 = bit(0, cl), v1 = bit(0, cl + 1), v2 = bit(0, cl + 2);
+            const uint32_t k0 = bit(1, cl) | (bit(2, cl) << 1), k1 = bit(1, cl + 1) | (bit(2, cl + 1) << 1), k2 = bit(1, cl + 2) | (bit(2, cl + 2) << 1);
+            return k0 | (v0 << 2) | (((k0 << 4) | (k1 << 2) | k2) << 8) | ((v0 & v1 & v2) << 14);
+        };
+        gmeta[tid] = meta_of(0);
+        gmeta2[tid] = meta_of(4);
+    }
+    __syncthreads();
+    // ---- thread (r, sub): the u16s of columns r and r + 16 of the workgroups sub, sub + 64, ...; runs of workgroups of
+    // one group in registers, then per (group, column) in LDS
+    auto hap_of = [&](int wg) -> int {
+        int h = 0;
+#pragma unroll
+        for (int k = 1; k < MSQ_MAX_HAPS; ++k)
+            if (k < f.n_haps && wg >= f.wg_first[k]) h = k;
+        return h;
+    };
+    if (any) {
+        uint32_t lo[kQ], hi[kQ], mg[3];
+        int cur = -1;
+        auto flush = [&]() {
+            if (cur >= 0) {
+#pragma unroll
+                for (int q = 0; q < kQ; ++q) {
+                    if (lo[q]) atomicAdd(&gacc[(cur * 34 + r) * kQ + q], lo[q]);
+                    if (hi[q]) atomicAdd(&gacc[(cur * 34 + r + 16) * kQ + q], hi[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (mg[q]) atomicAdd(&gacc[(cur * 34 + 32 + r) * kQ + 6 + q], mg[q]);  // r < 2 only
+            }
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) lo[q] = hi[q] = 0;
+            mg[0] = mg[1] = mg[2] = 0;
+        };
+        flush();
+        for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += kFoldRowsSubs * kFoldRowsTrip) {
+            if (wg0 != wg_lo + sub) load_trip(wg0);
+#pragma unroll
+            for (int u = 0; u < kFoldRowsTrip; ++u) {
+                if (wg0 + kFoldRowsSubs * u >= wg_hi) break;
+                const int h = f.n_haps > 1 ? hap_of(wg0 + kFoldRowsSubs * u) : 0;
+                if (h != cur) {
+                    flush();
+                    cur = h;
+                }
+#pragma unroll
+                for (int q = 0; q < kQ; ++q) {
+                    lo[q] += v[u][q] & 0xffffu;
+                    hi[q] += v[u][q] >> 16;
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) mg[q] += vm[u][q] & 0xffffu;
+            }
+        }
+        flush();
+    }
+    __syncthreads();
+    // ---- thread (column, group): the group's sums into bins, with the group's guide
+    {
+        const int cl = tid & 31, h = tid >> 5;
+        if (h < f.n_haps && cl < ncol && wgf[min(h, MSQ_MAX_HAPS - 1) + 1] > wgf[min(h, MSQ_MAX_HAPS - 1)]) {
+            const int wc = cb + cl;
+            const uint32_t* const ga = gacc + (h * 34 + cl) * kQ;
+            const uint32_t meta = gmeta[h * 32 + cl], meta2 = gmeta2[h * 32 + cl];
+            const uint32_t k0 = meta & 3u, cidx = (meta >> 8) & 63u;
+            uint32_t* const na = nuc_acc + cl * kNucStride;
+            uint32_t* const ca = cod_acc + cl * kCodStride;
+            if (ga[0]) atomicAdd(&na[k0], ga[0]);  // a count > 0 implies a valid base in that plane set
+            if (ga[1]) atomicAdd(&na[4], ga[1]);
+            if (ga[2]) atomicAdd(&ca[cidx], ga[2]);
+            if (ga[3]) atomicAdd(&na[5], ga[3]);
+            if (ga[4]) atomicAdd(&na[meta2 & 3u], ga[4]);
+            if (ga[5]) atomicAdd(&ca[(meta2 >> 8) & 63u], ga[5]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)  // MSAColumn::IncCounts: the base read at this column
+                if (const uint32_t n = ga[6 + k]) atomicAdd(&na[(k0 + 1u + (uint32_t)k) & 3u], n);
+            if (wc >= 1 && wc <= f.W - 3) {  // a column that can start a codon (MSARow::CodonAt's i > 0, CodingCodonAt's bound)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {  // the substitution sits in position q of the codon that starts here
+                    const int shift = 4 - 2 * q;
+                    const uint32_t kq = (cidx >> shift) & 3u;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (const uint32_t n = ga[q * kQ + 6 + k]) atomicAdd(&ca[(cidx & ~(3u << shift)) | (((kq + 1u + (uint32_t)k) & 3u) << shift)], n);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* const nuc = f.nuc + (size_t)cb * 6;
+    uint32_t* const codon = f.codon + (size_t)cb * 64;
+    if (f.dev_nuc) {
+        // msq_pileup_step: this block is the only writer of its columns (gridDim.y == 1, one launch): the matrices are
+        // STORED -- the fold's sums plus what the deviation path added to its own matrix, which is handed back cleared
+        uint32_t* const dev_nuc = f.dev_nuc + (size_t)cb * 6;
+        uint32_t* const dev_codon = f.dev_codon + (size_t)cb * 64;
+        if (tid < ncol * 64) {
+            codon[tid] = cod_acc[(tid >> 6) * kCodStride + (tid & 63)] + dev_c0;
+            if (dev_c0) dev_codon[tid] = 0;
+        }
+        if (tid + T < ncol * 64) {
+            const int i = tid + T;
+            codon[i] = cod_acc[(i >> 6) * kCodStride + (i & 63)] + dev_c1;
+            if (dev_c1) dev_codon[i] = 0;
+        }
+        if (tid < ncol * 6) {
+            nuc[tid] = nuc_acc[(tid / 6) * kNucStride + tid % 6] + dev_n;
+            if (dev_n) dev_nuc[tid] = 0;
+        }
+        return;
+    }
+    for (int i = tid; i < 32 * 64; i += T) {  // only columns inside the window hold anything
+        const uint32_t x = cod_acc[(i >> 6) * kCodStride + (i & 63)];
+        if (x) atomicAdd(&codon[i], x);
+    }
+    for (int i = tid; i < 32 * 6; i += T) {
+        const uint32_t x = nuc_acc[(i / 6) * kNucStride + i % 6];
+        if (x) atomicAdd(&nuc[i], x);
+    }
 }
 
 typedef void (*rows_kernel_fn)(RowsArgs);
@@ -663,7 +872,7 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
 
     // msq_pileup_noalloc: partials that would not fit the built-in buffer -> the read-space kernel (7 rows per workgroup
     // instead of 9) takes the call
-    if (fixed_partials && (size_t)ctx->n_cu * (NC + 6) * Gslab * 32 * 4 > fixed_bytes) return MSQ_OK;
+    if (fixed_partials && (size_t)ctx->n_cu * (NC + 5) * Gslab * 16 * 4 > fixed_bytes) return MSQ_OK;
 
     RowsArgs a;
     memset(&a, 0, sizeof(a));
@@ -705,7 +914,7 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
         const size_t lds = std::max(stream_lds, flush_wide ? slab_lds * n_roles : slab_lds);
         if (lds > 160 * 1024 - 512) return msq_fail(MSQ_ERR_ARG, "msq_pileup: no LDS for a %d-word slab", G);
         a.flush_wide = flush_wide ? 1u : 0u;
-        const size_t need = (size_t)n_wg * (NC + 6) * G * 32 * 4;
+        const size_t need = (size_t)n_wg * (NC + 5) * G * 16 * 4;
         void* sc = fixed_partials;
         if (fixed_partials) {
             if (need > fixed_bytes)
@@ -718,14 +927,17 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
         a.read_lo = lo;
         a.read_hi = hi;
         a.n_batches = (hi - lo + kRows - 1) / kRows;
-        FoldHaps fh;
-        fh.n = 1;
-        fh.wg_first[0] = 0;
-        fh.wg_first[1] = n_wg;
+        FoldRowsArgs fr;
+        memset(&fr, 0, sizeof(fr));
+        fr.n_haps = 1;
+        fr.wg_first[0] = 0;
+        for (int h = 1; h <= MSQ_MAX_HAPS; ++h) fr.wg_first[h] = n_wg;
+        fr.guides = R.guide;
         if (plan) {
             a.hp = *plan;
-            fh.n = plan->n;
-            for (int h = 0; h <= plan->n; ++h) fh.wg_first[h] = plan->wg_first[h];
+            fr.n_haps = plan->n;
+            for (int h = 0; h <= MSQ_MAX_HAPS; ++h) fr.wg_first[h] = plan->wg_first[h];
+            fr.guides = R.hap_guides;
         }
         if (!marked) {
             msq_timing_mark_begin(ctx);
@@ -735,10 +947,21 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
         hipLaunchKernelGGL(kern, dim3(n_wg), dim3(w * 64), lds, ctx->stream, a);
         if (last) msq_timing_mark_end(ctx);
         MSQ_HIP(hipGetLastError());
-        const int col_blocks = (G * 32 + kFoldCols - 1) / kFoldCols;
-        const int slices = d_dev ? 1 : std::max(1, std::min(n_wg / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
-        hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, a.partials, n_wg, NC, G * 32,
-                           a.slab_w0 * 32, W, d_nuc, d_codon, d_dev ? a.nuc : (uint32_t*)nullptr, d_dev ? a.codon : (uint32_t*)nullptr, NC + 6, fh);
+        const int slices = d_dev ? 1 : std::max(1, std::min(n_wg / (kFoldRowsSubs * kFoldRowsTrip), (ctx->n_cu / 2 + G - 1) / G));
+        fr.partials = a.partials;
+        fr.guide_words = R.guide_words;
+        fr.n_wg = n_wg;
+        fr.NC = NC;
+        fr.G = G;
+        fr.slab_w0 = a.slab_w0;
+        fr.Gtot = Gtot;
+        fr.word0 = a.word0;
+        fr.W = W;
+        fr.nuc = d_nuc;
+        fr.codon = d_codon;
+        fr.dev_nuc = d_dev ? a.nuc : nullptr;
+        fr.dev_codon = d_dev ? a.codon : nullptr;
+        hipLaunchKernelGGL(fold_rows_kernel, dim3(G, slices), dim3(1024), 0, ctx->stream, fr);
         MSQ_HIP(hipGetLastError());
         (void)slab;
         return MSQ_OK;

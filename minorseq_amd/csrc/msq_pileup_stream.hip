@@ -1637,8 +1637,7 @@ static int stream_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv_t
             const int col_blocks = (G * 32 + kFoldCols - 1) / kFoldCols;
             const int slices = fused ? 1 : std::max(1, std::min(n_wg / (kFoldSubs * kFoldTrip), (ctx->n_cu / 2 + col_blocks - 1) / col_blocks));
             hipLaunchKernelGGL(fold_partials_kernel, dim3(col_blocks, slices), dim3(kFoldCols * kFoldSubs), 0, ctx->stream, a.partials, n_wg,
-                               NC, G * 32, a.slab0, W, d_nuc, d_codon, fused ? a.nuc : (uint32_t*)nullptr, fused ? a.codon : (uint32_t*)nullptr, NC + 4,
-                               FoldHaps{1, {0, n_wg, 0, 0, 0, 0, 0, 0, 0}});
+                               NC, G * 32, a.slab0, W, d_nuc, d_codon, fused ? a.nuc : (uint32_t*)nullptr, fused ? a.codon : (uint32_t*)nullptr);
             MSQ_HIP(hipGetLastError());
         }
         if (phase) MSQ_HIP(hipStreamSynchronize(ctx->stream));  // the host position vectors and the scratch are reused

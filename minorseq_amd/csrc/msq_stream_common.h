@@ -131,45 +131,15 @@ __device__ __forceinline__ uint32_t codon_cols_of(int cg, int W)  // cg: word of
 // lanes: a thread has the loads of eight workgroups' partials in flight at once (the kernel is latency-bound: one
 // trip for 256 workgroups), the 32 lanes of a column meet in LDS, and what is not zero there leaves as one global
 // atomic per bin.  blockIdx.y slices the workgroups further (more blocks, but as many more global atomics).
-#ifndef MSQ_FOLD_COLS
-#define MSQ_FOLD_COLS 32
-#endif
-constexpr int kFoldCols = MSQ_FOLD_COLS, kFoldSubs = 1024 / kFoldCols, kFoldTrip = 256 / kFoldSubs;
-// rows: partial rows per workgroup -- NC + 4, or NC + 6 when the kernel also hands over its tables of isolated
-// substitutions (msq_pileup_rows.hip).  Those tables count by rank relative to the workgroup's guide, so they are summed
-// per haplotype group (FoldHaps: the workgroups wg_first[h] .. wg_first[h + 1] - 1 share a guide) and expanded with that
-// group's guide.
-struct FoldHaps {
-    int n;
-    int wg_first[9];
-};
+constexpr int kFoldCols = 32, kFoldSubs = 32, kFoldTrip = 8;
 __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols, int col0, int W,
                                               uint32_t* __restrict__ nuc, uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
-                                              uint32_t* __restrict__ dev_codon, int rows, const FoldHaps& fh)
+                                              uint32_t* __restrict__ dev_codon)
 {
     constexpr int kCodStride = 65, kNucStride = 7;  // odd strides: the lanes of a wave are columns
     __shared__ uint32_t cod_acc[kFoldCols * kCodStride];
     __shared__ uint32_t nuc_acc[kFoldCols * kNucStride];
-    constexpr int kSubStride = (kFoldCols + 2) * 3;
-    __shared__ uint32_t sub_acc[8 * kSubStride];  // per haplotype group: isolated substitutions of the block's columns and the next two, by rank
-    const bool with_subs = rows > NC + 4;
     const int T = kFoldCols * kFoldSubs, tid = threadIdx.x;
-    __shared__ int wgf[9];  // fh.wg_first where a thread indexes it by its own number
-    for (int i = tid; i < 8 * kSubStride; i += T) sub_acc[i] = 0;
-    if (tid < 9) {
-        int v = fh.wg_first[8];
-#pragma unroll
-        for (int k = 7; k >= 0; --k)
-            if (tid == k) v = fh.wg_first[k];
-        wgf[tid] = tid <= fh.n ? v : fh.wg_first[0];
-    }
-    auto hap_of = [&](int wg) -> int {
-        int h = 0;
-#pragma unroll
-        for (int k = 1; k < 8; ++k)
-            if (k < fh.n && wg >= fh.wg_first[k]) h = k;
-        return h;
-    };
     for (int i = tid; i < kFoldCols * kCodStride; i += T) cod_acc[i] = 0;
     for (int i = tid; i < kFoldCols * kNucStride; i += T) nuc_acc[i] = 0;
     const int cl = tid & (kFoldCols - 1), sub = tid / kFoldCols;
@@ -178,29 +148,12 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
     const int wg_lo = blockIdx.y * per, wg_hi = min(n_wg, wg_lo + per);
     const bool valid = c < cols && col0 + c < W;
     __syncthreads();
-    // thread `sub` of a column expands group `sub`'s substitution tables at the end: the group's guide at this column, as
-    // the group's first workgroup wrote it, is fetched now
-    const bool expands = with_subs && valid && sub < fh.n && wgf[min(sub, 7) + 1] > wgf[min(sub, 7)];
-    const uint32_t meta_of_group = expands ? partials[(size_t)wgf[min(sub, 7)] * rows * cols + (size_t)NC * cols + c] : 0u;
     if (valid) {
         uint32_t base[4] = {0, 0, 0, 0}, gap = 0, nn = 0;
         // codon counts: runs of workgroups that agree on the bin are added up before they cost an atomic (set 0 = the
         // guide's codon, set 1 = the alt haplotype's)
         uint32_t cod_sum[2] = {0, 0};
         int cod_idx[2] = {-1, -1};
-        // isolated substitutions (rows NC + 4, NC + 5) of this column, unpacked and summed; the codons one changes start
-        // up to two columns before it: the threads of columns 0 and 1 also sum the next block's columns 0 and 1
-        uint32_t sr[3] = {0, 0, 0};
-        int sr_hap = -1;  // runs of workgroups of one group are added up before they go to LDS
-        const bool margin = with_subs && cl < 2 && c + kFoldCols < cols;
-        auto flush_subs = [&](int at) {
-            if (sr_hap >= 0) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    if (sr[r]) atomicAdd(&sub_acc[sr_hap * kSubStride + at * 3 + r], sr[r]);
-            }
-            sr[0] = sr[1] = sr[2] = 0;
-        };
         auto add_codon = [&](int set, uint32_t meta, uint32_t n) {
             if (!n) return;
             const int idx = (int)((meta >> 8) & 63u);
@@ -213,13 +166,10 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
         };
         for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += kFoldSubs * kFoldTrip) {
             uint32_t meta[kFoldTrip], m[kFoldTrip], g[kFoldTrip], cm[kFoldTrip], n4[kFoldTrip], am[kFoldTrip], acm[kFoldTrip], meta2[kFoldTrip];
-            uint32_t sa[kFoldTrip], sb[kFoldTrip];  // substitution tables of this column
 #pragma unroll
             for (int u = 0; u < kFoldTrip; ++u) {
                 const int wg = min(wg0 + kFoldSubs * u, wg_hi - 1);  // clamped: a slot past the end is loaded and ignored
-                const uint32_t* p = partials + (size_t)wg * rows * cols;
-                sa[u] = with_subs ? p[(size_t)(NC + 4) * cols + c] : 0u;
-                sb[u] = with_subs ? p[(size_t)(NC + 5) * cols + c] : 0u;
+                const uint32_t* p = partials + (size_t)wg * (NC + 4) * cols;
                 meta[u] = p[(size_t)NC * cols + c];
                 m[u] = p[c];
                 g[u] = p[(size_t)cols + c];
@@ -239,45 +189,7 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
                 nn += n4[u];
                 add_codon(0, meta[u], cm[u]);
                 add_codon(1, meta2[u], acm[u]);
-                if (with_subs) {
-                    const int h = fh.n > 1 ? hap_of(wg0 + kFoldSubs * u) : 0;
-                    if (h != sr_hap) {
-                        flush_subs(cl);
-                        sr_hap = h;
-                    }
-                    sr[0] += sa[u] & 0xffffu;
-                    sr[1] += sa[u] >> 16;
-                    sr[2] += sb[u];
-                }
             }
-        }
-        flush_subs(cl);
-        sr_hap = -1;
-        if (margin) {  // a trip of its own (two lanes of 32): kept out of the main trip, whose registers are full
-            for (int wg0 = wg_lo + sub; wg0 < wg_hi; wg0 += kFoldSubs * kFoldTrip) {
-                uint32_t sa[kFoldTrip], sb[kFoldTrip];
-#pragma unroll
-                for (int u = 0; u < kFoldTrip; ++u) {
-                    const int wg = min(wg0 + kFoldSubs * u, wg_hi - 1);
-                    const uint32_t* p = partials + (size_t)wg * rows * cols + c + kFoldCols;
-                    const bool in = wg0 + kFoldSubs * u < wg_hi;
-                    sa[u] = in ? p[(size_t)(NC + 4) * cols] : 0u;
-                    sb[u] = in ? p[(size_t)(NC + 5) * cols] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < kFoldTrip; ++u) {
-                    if (wg0 + kFoldSubs * u >= wg_hi) break;
-                    const int h = fh.n > 1 ? hap_of(wg0 + kFoldSubs * u) : 0;
-                    if (h != sr_hap) {
-                        flush_subs(kFoldCols + cl);
-                        sr_hap = h;
-                    }
-                    sr[0] += sa[u] & 0xffffu;
-                    sr[1] += sa[u] >> 16;
-                    sr[2] += sb[u];
-                }
-            }
-            flush_subs(kFoldCols + cl);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -287,29 +199,6 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
 #pragma unroll
         for (int set = 0; set < 2; ++set)
             if (cod_sum[set]) atomicAdd(&cod_acc[cl * kCodStride + cod_idx[set]], cod_sum[set]);
-    }
-    if (with_subs) {
-        __syncthreads();
-        if (expands) {
-            const uint32_t meta = meta_of_group;
-            const uint32_t* const sa = sub_acc + sub * kSubStride;
-            const uint32_t k0 = meta & 3u, cidx = (meta >> 8) & 63u;
-            const int wc = col0 + c;  // window column
-#pragma unroll
-            for (int r = 0; r < 3; ++r)  // MSAColumn::IncCounts: the base read at this column
-                if (const uint32_t n = sa[cl * 3 + r]) atomicAdd(&nuc_acc[cl * kNucStride + ((k0 + 1u + (uint32_t)r) & 3u)], n);
-            if (wc >= 1 && wc <= W - 3) {  // a column that can start a codon (MSARow::CodonAt's i > 0, CodingCodonAt's bound)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {  // the substitution sits in position q of the codon that starts here
-                    const int shift = 4 - 2 * q;
-                    const uint32_t kq = (cidx >> shift) & 3u;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        if (const uint32_t n = sa[(cl + q) * 3 + r])
-                            atomicAdd(&cod_acc[cl * kCodStride + ((cidx & ~(3u << shift)) | (((kq + 1u + (uint32_t)r) & 3u) << shift))], n);
-                }
-            }
-        }
     }
     __syncthreads();
     const int cb = col0 + blockIdx.x * kFoldCols;  // window column of the block's column 0
@@ -344,9 +233,9 @@ __device__ __forceinline__ void fold_partials(const uint32_t* __restrict__ parti
 __attribute__((unused)) __global__ __launch_bounds__(kFoldCols* kFoldSubs) void fold_partials_kernel(const uint32_t* __restrict__ partials, int n_wg, int NC, int cols,
                                                                              int col0, int W, uint32_t* __restrict__ nuc,
                                                                              uint32_t* __restrict__ codon, uint32_t* __restrict__ dev_nuc,
-                                                                             uint32_t* __restrict__ dev_codon, int rows, FoldHaps fh)
+                                                                             uint32_t* __restrict__ dev_codon)
 {
-    fold_partials(partials, n_wg, NC, cols, col0, W, nuc, codon, dev_nuc, dev_codon, rows, fh);
+    fold_partials(partials, n_wg, NC, cols, col0, W, nuc, codon, dev_nuc, dev_codon);
 }
 
 // the folds of a merged launch as one launch: blockIdx.z = the slab
@@ -359,11 +248,7 @@ __attribute__((unused)) __global__ __launch_bounds__(kFoldCols* kFoldSubs) void 
 {
     const int sl = blockIdx.z;
     if ((int)blockIdx.x * kFoldCols >= t.cols[sl]) return;  // the grid is as wide as the widest slab
-    FoldHaps fh;
-    fh.n = 1;
-    fh.wg_first[0] = 0;
-    fh.wg_first[1] = t.n_wg[sl];
-    fold_partials(t.partials[sl], t.n_wg[sl], NC, t.cols[sl], t.col0[sl], W, nuc, codon, nullptr, nullptr, NC + 4, fh);
+    fold_partials(t.partials[sl], t.n_wg[sl], NC, t.cols[sl], t.col0[sl], W, nuc, codon, nullptr, nullptr);
 }
 
 
