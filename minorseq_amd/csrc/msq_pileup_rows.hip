@@ -48,6 +48,7 @@ __device__ unsigned long long rows_dbg[8];  // entries, drains, nucleotide atomi
 #define ROWS_DBG(i, n) ((void)0)
 #endif
 constexpr int kRowsWaves = 12;     // waves per workgroup (one workgroup per CU, 3 waves per SIMD: 168 VGPRs, nothing spills)
+constexpr int kRowsWavesN = 8;     // ... of the variant with an N counter (a fourth counter set: 2 waves per SIMD rather than spills)
 constexpr int kQueueCap = 384;     // entries of a wave's deviation queue: 16 B of planes + a 4-byte tag each
 constexpr int kQueueRoom = 128;    // two reads add at most this many entries: drained when fewer slots are left
 constexpr int kQueueDrainAt = 192; // at the end of a batch: drain when at least this many entries wait (three full waves of lanes: a drain ends with vmcnt(0), a bubble in the load pipeline)
@@ -106,7 +107,7 @@ struct RowTable {
 };
 
 template <bool MANY_N>
-__global__ __launch_bounds__(kRowsWaves * 64) void pileup_rows_kernel(RowsArgs a)
+__global__ __launch_bounds__((MANY_N ? kRowsWavesN : kRowsWaves) * 64) void pileup_rows_kernel(RowsArgs a)
 {
     constexpr int NC = MANY_N ? 4 : 3;
     constexpr bool COUNT_N = MANY_N;
@@ -972,7 +973,7 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
         a.G = G;
         a.slab_w0 = slab * Gslab;
         a.n_roles = n_roles;
-        const int wr_full = kRowsWaves / n_roles;  // waves per role
+        const int wr_full = (many_n ? kRowsWavesN : kRowsWaves) / n_roles;  // waves per role
         // every role sees every batch: a workgroup counts (waves of a role) x 127 batches
         const uint64_t reads_per_launch = (uint64_t)ctx->n_cu * wr_full * kMaxBatchesPerWave * kRows;
         if (d_step_bounds && R.n_reads > reads_per_launch) return marked ? msq_fail(MSQ_ERR_ARG, "msq_pileup_step: internal") : MSQ_OK;
