@@ -85,8 +85,7 @@ struct RowsArgs {
     uint32_t* codon;
     uint32_t* partials;  // [workgroups][NC + 5][G * 16]: u16 pairs, columns r and r + 16 of a word share a u32
     uint32_t* err;
-    uint32_t* bounds_acc;  // msq_pileup_step: the shard's bounds come out of this launch too (NULL otherwise)
-    int32_t* bounds_out;
+    uint32_t* bounds_slots;  // msq_pileup_step: [workgroups][2], every workgroup's share of the shard's bounds (keyed maxima); the fold finishes them (NULL otherwise)
 };
 
 __device__ __forceinline__ uint32_t dpp_next_lane(uint32_t v)  // lane i <- lane i + 1, lane 63 <- 0 (wave_shl:1)
@@ -173,7 +172,7 @@ __global__ __launch_bounds__((MANY_N ? kRowsWavesN : kRowsWaves) * 64) void pile
     for (int i = tid; i < 3 * G * 32; i += T) altc[i] = 0;  // alt counters and both substitution tables
     // (msq_pileup_step) this workgroup's share of the shard's reads for the window bounds
     int32_t b_lo = INT32_MAX, b_hi = INT32_MIN;
-    const bool with_bounds = a.bounds_acc != nullptr;
+    const bool with_bounds = a.bounds_slots != nullptr;
     if (with_bounds) {
 #pragma unroll 4
         for (uint64_t i = a.read_lo + (uint64_t)blockIdx.x * T + tid; i < a.read_hi; i += (uint64_t)gridDim.x * T) {
@@ -502,19 +501,7 @@ __global__ __launch_bounds__((MANY_N ? kRowsWavesN : kRowsWaves) * 64) void pile
 #pragma unroll
     for (int l = 0; l < kLevels; ++l) cnt[2][l] &= ccols;  // columns that cannot start a codon were counted along
     __syncthreads();
-    if (with_bounds && tid == 0) {  // the last workgroup in publishes the bounds and clears the accumulators
-        atomicMax(&a.bounds_acc[0], draw_ctr[2]);
-        atomicMax(&a.bounds_acc[1], draw_ctr[3]);
-        __threadfence();
-        if (atomicAdd(&a.bounds_acc[2], 1u) == gridDim.x - 1) {
-            __threadfence();
-            const uint32_t k_lo = atomicExch(&a.bounds_acc[0], 0u), k_hi = atomicExch(&a.bounds_acc[1], 0u);
-            atomicExch(&a.bounds_acc[2], 0u);
-            const int32_t begin0 = (int32_t)(~k_lo ^ 0x80000000u), end0 = (int32_t)(k_hi ^ 0x80000000u);
-            a.bounds_out[0] = -begin0;
-            a.bounds_out[1] = end0 > 0 ? end0 : 0;
-        }
-    }
+    if (with_bounds && tid < 2) a.bounds_slots[2 * wg + tid] = draw_ctr[2 + tid];  // no atomics: 256 workgroups end together, and the fold comes anyway
     // no workgroup counts 65 536 reads, so a partial holds u16s, two to a u32: columns r and r + 16 of a 32-column word --
     // the way the transposed counters come out.  Rows: the NC counters, the alt nucleotide and codon counts, the three
     // ranks of the isolated substitutions; the fold works the guides' bins out from the guides themselves
@@ -592,6 +579,8 @@ struct FoldRowsArgs {
     int n_haps;
     int wg_first[MSQ_MAX_HAPS + 1];
     uint32_t *nuc, *codon, *dev_nuc, *dev_codon;
+    const uint32_t* bounds_slots;  // msq_pileup_step: the workgroups' shares of the shard's bounds; block 0 finishes them
+    int32_t* bounds_out;
 };
 constexpr int kFoldRowsSubs = 64, kFoldRowsTrip = 4;  // 16 lanes (a u32 = columns r and r + 16) x 64 subs; 4 workgroups per thread and trip
 
@@ -603,6 +592,7 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(FoldRowsArgs f)
     __shared__ uint32_t gacc[MSQ_MAX_HAPS * 34 * kQ];  // columns 32, 33: the next word's first two (substitution ranks only)
     __shared__ uint32_t gmeta[MSQ_MAX_HAPS * 32], gmeta2[MSQ_MAX_HAPS * 32];
     __shared__ int wgf[MSQ_MAX_HAPS + 1];
+    __shared__ uint32_t bmax[2];
     const int T = 1024, tid = threadIdx.x, r = tid & 15, sub = tid >> 4, NC = f.NC, G = f.G;
     const int w = blockIdx.x;              // word of the slab
     const int cb = (f.slab_w0 + w) * 32;   // window column of the block's column 0
@@ -618,6 +608,13 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(FoldRowsArgs f)
         if (tid + T < ncol * 64) dev_c1 = f.dev_codon[(size_t)cb * 64 + tid + T];
         if (tid < ncol * 6) dev_n = f.dev_nuc[(size_t)cb * 6 + tid];
     }
+    const bool does_bounds = f.bounds_slots && blockIdx.x == 0 && blockIdx.y == 0;
+    uint32_t bk_lo = 0, bk_hi = 0;  // keyed maxima: 0 is below every key
+    if (does_bounds)
+        for (int i = tid; i < f.n_wg; i += T) {
+            bk_lo = max(bk_lo, f.bounds_slots[2 * i]);
+            bk_hi = max(bk_hi, f.bounds_slots[2 * i + 1]);
+        }
     uint32_t g0[8], g1[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) g0[k] = g1[k] = 0;
@@ -656,6 +653,7 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(FoldRowsArgs f)
     for (int i = tid; i < 32 * kCodStride; i += T) cod_acc[i] = 0;
     for (int i = tid; i < 32 * kNucStride; i += T) nuc_acc[i] = 0;
     for (int i = tid; i < MSQ_MAX_HAPS * 34 * kQ; i += T) gacc[i] = 0;
+    if (tid < 2) bmax[tid] = 0;
     if (tid <= MSQ_MAX_HAPS) {
         int x = f.wg_first[MSQ_MAX_HAPS];
 #pragma unroll
@@ -675,6 +673,10 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(FoldRowsArgs f)
         gmeta2[tid] = meta_of(4);
     }
     __syncthreads();
+    if (does_bounds) {  // UpdateBoundaries over the shard (src/MSA.cpp:96-97,138-142): the maxima of the workgroups' keyed shares
+        if (bk_lo) atomicMax(&bmax[0], bk_lo);
+        if (bk_hi) atomicMax(&bmax[1], bk_hi);
+    }
     // ---- thread (r, sub): the u16s of columns r and r + 16 of the workgroups sub, sub + 64, ...; runs of workgroups of
     // one group in registers, then per (group, column) in LDS
     auto hap_of = [&](int wg) -> int {
@@ -757,6 +759,11 @@ __global__ __launch_bounds__(1024) void fold_rows_kernel(FoldRowsArgs f)
         }
     }
     __syncthreads();
+    if (does_bounds && tid == 0) {
+        const int32_t begin0 = (int32_t)(~bmax[0] ^ 0x80000000u), end0 = (int32_t)(bmax[1] ^ 0x80000000u);
+        f.bounds_out[0] = -begin0;
+        f.bounds_out[1] = end0 > 0 ? end0 : 0;
+    }
     uint32_t* const nuc = f.nuc + (size_t)cb * 6;
     uint32_t* const codon = f.codon + (size_t)cb * 64;
     if (f.dev_nuc) {
@@ -873,7 +880,7 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
 
     // msq_pileup_noalloc: partials that would not fit the built-in buffer -> the read-space kernel (7 rows per workgroup
     // instead of 9) takes the call
-    if (fixed_partials && (size_t)ctx->n_cu * (NC + 5) * Gslab * 16 * 4 > fixed_bytes) return MSQ_OK;
+    if (fixed_partials && (size_t)ctx->n_cu * ((NC + 5) * Gslab * 16 * 4 + 8) > fixed_bytes) return MSQ_OK;
 
     RowsArgs a;
     memset(&a, 0, sizeof(a));
@@ -891,10 +898,7 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
     a.nuc = d_dev ? d_dev : d_nuc;
     a.codon = d_dev ? d_dev + (size_t)W * 6 : d_codon;
     a.err = ctx->d_err;
-    if (d_step_bounds) {
-        a.bounds_acc = ctx->d_small + 16;
-        a.bounds_out = d_step_bounds;
-    }
+
     rows_kernel_fn kern = pick_rows_kernel(many_n);
     bool marked = false;
     // haplotype groups (msq_reads_align): the workgroups are dealt out among the groups in proportion to their reads
@@ -915,7 +919,8 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
         const size_t lds = std::max(stream_lds, flush_wide ? slab_lds * n_roles : slab_lds);
         if (lds > 160 * 1024 - 512) return msq_fail(MSQ_ERR_ARG, "msq_pileup: no LDS for a %d-word slab", G);
         a.flush_wide = flush_wide ? 1u : 0u;
-        const size_t need = (size_t)n_wg * (NC + 5) * G * 16 * 4;
+        const size_t part_bytes = (size_t)n_wg * (NC + 5) * G * 16 * 4;
+        const size_t need = part_bytes + (d_step_bounds ? (size_t)n_wg * 8 : 0);  // + the workgroups' shares of the bounds
         void* sc = fixed_partials;
         if (fixed_partials) {
             if (need > fixed_bytes)
@@ -925,6 +930,7 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
             if (rc != MSQ_OK) return rc;
         }
         a.partials = static_cast<uint32_t*>(sc);
+        a.bounds_slots = d_step_bounds ? reinterpret_cast<uint32_t*>(static_cast<char*>(sc) + part_bytes) : nullptr;
         a.read_lo = lo;
         a.read_hi = hi;
         a.n_batches = (hi - lo + kRows - 1) / kRows;
@@ -962,6 +968,8 @@ int msq_pileup_rows_launch(msq_ctx* ctx, const msq_packed_reads& R, const msq_qv
         fr.codon = d_codon;
         fr.dev_nuc = d_dev ? a.nuc : nullptr;
         fr.dev_codon = d_dev ? a.codon : nullptr;
+        fr.bounds_slots = a.bounds_slots;
+        fr.bounds_out = d_step_bounds;
         hipLaunchKernelGGL(fold_rows_kernel, dim3(G, slices), dim3(1024), 0, ctx->stream, fr);
         MSQ_HIP(hipGetLastError());
         (void)slab;
