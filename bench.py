@@ -667,7 +667,9 @@ def main():
         # + 4 B per group of column index when the set carries one and the kernel variant uses it (no QV planes to read)
         aligned = run.aligned
         indexed = (not aligned) and bool(run.dr.view.gcol) and (baked or planes == 0) and a.mode != "simple"
-        real_bytes = n_bases / 32 * (16 + 32 * (0 if (baked or aligned) else planes) + (4 if indexed else 0)) + (20.0 if aligned else 12.0) * shard_reads
+        groups = int(run.dr.view.hap_count) if aligned else 0  # haplotype groups: + 4 B/read of the group-ordered read list
+        per_read = (24.0 if groups >= 2 else 20.0) if aligned else 12.0
+        real_bytes = n_bases / 32 * (16 + 32 * (0 if (baked or aligned) else planes) + (4 if indexed else 0)) + per_read * shard_reads
         kernel_name = "pileup_simple_kernel" if a.mode == "simple" else "pileup_rows_kernel" if aligned else "pileup_kernel"
         traffic = None if (a.rich or a.scaling == "strong" and world > 1) else load_traffic(kernel_name, wl.name, shard_reads, a.qualqv, baked)
         physical = (traffic or real_bytes) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -675,8 +677,9 @@ def main():
         # a leaner format than 1.5 B/base may exceed frac 1 only by reading less -- state the format
         qv_read = 0 if baked else planes
         fmt = ("column-aligned groups (msq_reads_align at set-up: a group = a 32-column word of its read's row, 2-bit nucleotide + 2-bit op "
-               "per column, inserted bases left out): 0.5 B per column-consuming base + 20 B/read of tables; no QV plane, no column index "
-               "read; algorithmic bytes price 1.5 B/base as SURVEY 8d states them") if aligned else \
+               "per column, inserted bases left out): 0.5 B per column-consuming base + %d B/read of tables%s; no QV plane, no column index "
+               "read; algorithmic bytes price 1.5 B/base as SURVEY 8d states them"
+               % (per_read, " and read list (%d haplotype groups, each counted against its own guide)" % groups if groups >= 2 else "")) if aligned else \
               "0.5 B/base bit planes (2-bit nucleotide + 2-bit op, sliced per 32-base group)" + \
               (" + 0.125 B/base group column index" if indexed else "") + " + 12 B/read; " + \
               ("%d QV plane%s read in the pass (1 B/base each)" % (qv_read, "" if qv_read == 1 else "s") if qv_read else
@@ -707,7 +710,7 @@ def main():
                 "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 125) // 126 if run.aligned else (((W + 31) // 32) + 127) // 128),
                 "pileup_launches_per_step": run.launches_per_step,
                 "read_layout": ("column-slab partition (built at set-up)" if n_slabs else
-                                "one read set, column-aligned (msq_reads_align at set-up: %.1f ms)" % run.align_ms if aligned else "one read set, normalized groups"),
+                                "one read set, column-aligned (msq_reads_align at set-up: %.1f ms; %s)" % (run.align_ms, "%d haplotype groups" % groups if groups >= 2 else "one population") if aligned else "one read set, normalized groups"),
                 "qv_thresholds": "unset" if a.qualqv < 0 and not a.rich else "applied at pack time (baked; the bake pass is set-up, not timed)" if baked else "applied in every pass",
                 "clock_spinup": ("%d untimed steps (%.0f ms) at the end of set-up, before the warm-up steps" % (run.spinup_steps, a.spinup_ms)
                                  if run.spinup_steps else "none"),
