@@ -61,6 +61,12 @@ def test_fuzz(ctx, seed):
             assert (nuc.cpu().numpy()[:m.W * 6].reshape(-1, 6) == m.nuc_counts()).all(), plain
             assert (codon.cpu().numpy()[:m.W * 64].reshape(-1, 64) == m.codon_counts()).all(), plain
             codon = codon[:m.W * 64].contiguous()
+        if reads["n_reads"]:  # the set aligned under its thresholds (msq_reads_align): the aligned-set kernel, or -- exotic symbols -- the fallback
+            al = device.align(ctx, dr, q, b0 - 32 * (seed % 3))  # the window 0, 1 or 2 words right of the set's origin
+            nuc, codon = device.pileup(ctx, al, abi.QvThresholds.make(), b0, m.W)
+            assert (nuc.cpu().numpy()[:m.W * 6].reshape(-1, 6) == m.nuc_counts()).all(), ("aligned", plain)
+            assert (codon.cpu().numpy()[:m.W * 64].reshape(-1, 64) == m.codon_counts()).all(), ("aligned", plain)
+            al.close()
         baked = device.bake_qv(ctx, dr, q)  # thresholds applied at pack time: same counts with no thresholds left
         for mode in (abi.MSQ_PILEUP_AUTO, abi.MSQ_PILEUP_SIMPLE):
             nuc, codon = device.pileup(ctx, baked, abi.QvThresholds.make(-1, -1, -1, -1), b0, m.W, mode=mode)
