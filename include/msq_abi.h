@@ -29,7 +29,9 @@ enum msq_status {
     MSQ_ERR_RANGE = -6,    /* std::out_of_range: referenceSequence.substr(absPos,3) src/AminoAcidCaller.cpp:446,
                               or a factorial argument beyond the reserved log-factorial table */
     MSQ_ERR_NODEVICE = -7, /* no usable GPU: the product path has no CPU fallback */
-    MSQ_ERR_NOMEM = -8
+    MSQ_ERR_NOMEM = -8,
+    MSQ_ERR_DATA = -9      /* the BAM front on the device: a BGZF block that does not inflate to its ISIZE, a record
+                              chain or record the host front (cpp/msq_bam.hpp) would refuse */
 };
 
 typedef struct msq_ctx msq_ctx;
@@ -483,6 +485,69 @@ int msq_error_model_from_rates(double substitution_rate, double deletion_rate, m
 int msq_rows_decode(msq_ctx* ctx, const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, int32_t win_begin0,
                     int32_t W, uint64_t first_read, uint64_t n_rows, char* d_rows /* [n_rows][W] */);
 
+/* ------------------------------------------------------------------------------- the BAM front on the device
+ * IO::BamUtils::BamToArrayReads (src/BamUtils.cpp:56-78) + BAMArrayRead's constructor (src/ArrayRead.cpp:53-99)
+ * without pbbam AND without the host in the data path (cpp/msq_bam.hpp is the host front these calls
+ * replace stage by stage): the file image crosses PCIe once, compressed; BGZF members are inflated one wave each
+ * (csrc/msq_bgzf.hip), the record chain is found and checked, records are filtered (primary alignments that overlap
+ * the region, BamUtils.cpp:69-71), measured (reference interval, ArrayBases inside the region) and decoded straight
+ * into the packed set the pileup reads (csrc/msq_bamdev.hip); only the small per-record table and the names come back.
+ * A file the host front would refuse or that needs one of its exceptions (a block that does not inflate, a malformed
+ * record, a bad cigar op, a cigar the MSA throws on) makes the call return MSQ_ERR_DATA: the caller then runs the
+ * host front, which reports the error in file order as before.  Parity unpinned at the pbbam boundary, as for the
+ * host front; the tests check byte equality with zlib and with the host front's packed sets. */
+typedef struct msq_bgzf_member {
+    uint64_t in_off;  /* of the member's DEFLATE payload in the file image */
+    uint64_t out_off; /* where it inflates to: members follow each other in the output */
+    uint32_t in_len;  /* payload bytes (BSIZE + 1 - header - 8) */
+    uint32_t out_len; /* ISIZE, <= 65536 */
+} msq_bgzf_member;
+typedef struct msq_bam_dev msq_bam_dev; /* a BAM file's inflated stream (and, after msq_bam_index_device, its record tables) in HBM */
+/* host arrays in (the file image may be a pageable mapping); synchronises.  zlib's inflate of every member, bit for bit. */
+int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64_t file_bytes, const msq_bgzf_member* members,
+                            uint64_t n_members, msq_bam_dev** out);
+uint64_t msq_bam_dev_bytes(const msq_bam_dev* bam);
+/* bytes [off, off + len) of the inflated stream to the host (the BAM header; tests); synchronises */
+int msq_bam_dev_read(msq_ctx* ctx, const msq_bam_dev* bam, uint64_t off, uint64_t len, void* host_dst);
+int msq_bam_dev_free(msq_ctx* ctx, msq_bam_dev* bam);
+
+enum msq_bam_rec_status {
+    MSQ_BAM_REC_SKIP = 0,      /* secondary, supplementary, unmapped or outside the region (BamUtils.cpp:69-71) */
+    MSQ_BAM_REC_KEEP = 1,
+    MSQ_BAM_REC_MALFORMED = 2, /* fields that do not fit the record's block_size */
+    MSQ_BAM_REC_CIGAR = 3,     /* a cigar op > 8, or a cigar longer than SEQ */
+    MSQ_BAM_REC_MSA = 4        /* an 'M' or 'N' run inside the region: MSAByRow::AddRead throws on it (src/MSA.cpp:182) */
+};
+typedef struct msq_bam_record {
+    uint64_t body_off;  /* of the record's body (behind block_size) in the inflated stream */
+    int64_t n_bases;    /* ArrayBases BAMArrayRead would hold: the alignment columns inside the region, clips excised */
+    uint32_t block_size;
+    int32_t ref_start, ref_end; /* pos, pos + the cigar's reference length (unclipped) */
+    uint32_t l_seq;
+    uint32_t sq_off, dq_off, iq_off; /* the sq / dq / iq values from the body's start when all three are there with
+                                        l_seq chars (rich QVs, ArrayRead.cpp:74-79), else all 0 */
+    uint16_t n_cigar, flag;
+    uint8_t l_read_name;
+    uint8_t status;   /* msq_bam_rec_status */
+    uint8_t rg_len;   /* length of the RG:Z value, 255 without one, 254 when longer than rg[] */
+    uint8_t has_qual; /* QUAL present (first byte != 0xFF); QualQV 0 for every base otherwise (ArrayRead.cpp:94-96) */
+    char rg[16];
+    uint32_t pad_;
+} msq_bam_record;
+/* The record chain from first_record_off (the byte behind the BAM header) to the end of the stream, every record's
+ * consistency, the filters and measurements above; region as BamToArrayReads computes it (0-based, [start, end)).
+ * MSQ_ERR_DATA unless the chain ends exactly at the end of the stream and no record is malformed.  Synchronises. */
+int msq_bam_index_device(msq_ctx* ctx, msq_bam_dev* bam, uint64_t first_record_off, int32_t n_ref, int32_t region_start0,
+                         int32_t region_end0, uint64_t* n_records, uint64_t* n_kept);
+/* the kept records' table, and their names back to back (l_read_name bytes each, NUL included), to the host */
+int msq_bam_records(msq_ctx* ctx, const msq_bam_dev* bam, msq_bam_record* host_kept /* [n_kept] */);
+int msq_bam_names(msq_ctx* ctx, const msq_bam_dev* bam, char* host_buf, uint64_t buf_bytes);
+/* Kept records [first, first + count) decoded and packed on the device: the same packed set, bit for bit, as
+ * msq_pack_reads_device_fill_compact fed by the host front's decoder (thresholds applied while decoding; pack_flags as
+ * there).  MSQ_ERR_DATA when one of them has a status other than KEEP.  Synchronises. */
+int msq_bam_pack_device(msq_ctx* ctx, const msq_bam_dev* bam, uint64_t first, uint64_t count, uint32_t pack_flags,
+                        const msq_qv_thresholds* thr, msq_packed_dev** out);
+
 /* Diagnostics (no counterpart in the reference; tests ask which path a call took): pileup calls of this process that
  * ran the slabs of a wide window as one merged launch; msq_phase_codons calls that took the lookup gather.  (An
  * experiment build with -DMSQ_WGT also exports msq_debug_wgt, per-workgroup clocks for tools/wgt.py; the shipped
@@ -496,6 +561,7 @@ int msq_debug_phase_lookups(void);
 #define MSQ_TUNE_NO_MERGE 1
 #define MSQ_TUNE_CARRIER_MIN_BATCHES 2
 #define MSQ_TUNE_NO_HAPS 3 /* msq_reads_align makes no haplotype groups (MSQ_NO_HAPS in the environment) */
+#define MSQ_TUNE_BAM_SEGMENT 4 /* msq_bam_index_device: bytes per segment of the record-start search (default 16384, >= 64) */
 int msq_debug_tune(msq_ctx* ctx, int key, long long value);
 /* tools: event counts of the aligned-set pileup kernel since the last call -- {queue entries, drains, nucleotide atomics,
  * codon atomics, alt-haplotype LDS adds, isolated-substitution LDS adds, 0, 0}; all zero unless the library was built

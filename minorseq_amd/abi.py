@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, os.environ.get("MSQ_LIB_DIR", "lib"), "libmsq_hip
 MSQ_OK = 0
 MSQ_ERR_ARG, MSQ_ERR_HIP, MSQ_ERR_CIGAR, MSQ_ERR_BASE = -1, -2, -3, -4
 MSQ_ERR_WINDOW, MSQ_ERR_RANGE, MSQ_ERR_NODEVICE, MSQ_ERR_NOMEM = -5, -6, -7, -8
+MSQ_ERR_DATA = -9
 MSQ_PILEUP_AUTO, MSQ_PILEUP_SIMPLE, MSQ_PILEUP_STREAM, MSQ_PILEUP_ROWS = 0, 1, 2, 3
 MSQ_READS_HAS_EXOTIC = 1
 MSQ_READS_NORMALIZED = 2
@@ -22,6 +23,8 @@ MSQ_READS_INS_EXOTIC = 16
 MSQ_READS_ALIGNED = 32
 MSQ_PACK_PLAIN = 1
 MSQ_COMM_ID_BYTES = 128
+MSQ_TUNE_NO_MERGE, MSQ_TUNE_CARRIER_MIN_BATCHES, MSQ_TUNE_NO_HAPS, MSQ_TUNE_BAM_SEGMENT = 1, 2, 3, 4
+MSQ_BAM_REC_SKIP, MSQ_BAM_REC_KEEP, MSQ_BAM_REC_MALFORMED, MSQ_BAM_REC_CIGAR, MSQ_BAM_REC_MSA = 0, 1, 2, 3, 4
 
 
 class MsqError(RuntimeError):
@@ -69,6 +72,32 @@ class Position(C.Structure):
 
 class ErrorModel(C.Structure):
     _fields_ = [("match", C.c_double), ("substitution", C.c_double), ("deletion", C.c_double)]
+
+
+class BgzfMember(C.Structure):
+    _fields_ = [("in_off", C.c_uint64), ("out_off", C.c_uint64), ("in_len", C.c_uint32), ("out_len", C.c_uint32)]
+
+
+class BamRecord(C.Structure):
+    _fields_ = [
+        ("body_off", C.c_uint64),
+        ("n_bases", C.c_int64),
+        ("block_size", C.c_uint32),
+        ("ref_start", C.c_int32),
+        ("ref_end", C.c_int32),
+        ("l_seq", C.c_uint32),
+        ("sq_off", C.c_uint32),
+        ("dq_off", C.c_uint32),
+        ("iq_off", C.c_uint32),
+        ("n_cigar", C.c_uint16),
+        ("flag", C.c_uint16),
+        ("l_read_name", C.c_uint8),
+        ("status", C.c_uint8),
+        ("rg_len", C.c_uint8),
+        ("has_qual", C.c_uint8),
+        ("rg", C.c_char * 16),
+        ("pad_", C.c_uint32),
+    ]
 
 
 class SynthParams(C.Structure):
@@ -131,6 +160,14 @@ _SIGNATURES = {
     "msq_pileup_noalloc": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, _P, _P]),
     "msq_pileup_check": (C.c_int, [_P]),
     "msq_rows_decode": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P]),
+    "msq_bgzf_inflate_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(_P)]),
+    "msq_bam_dev_bytes": (C.c_uint64, [_P]),
+    "msq_bam_dev_read": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P]),
+    "msq_bam_dev_free": (C.c_int, [_P, _P]),
+    "msq_bam_index_device": (C.c_int, [_P, _P, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "msq_bam_records": (C.c_int, [_P, _P, _P]),
+    "msq_bam_names": (C.c_int, [_P, _P, _P, C.c_uint64]),
+    "msq_bam_pack_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(QvThresholds), C.POINTER(_P)]),
     "msq_debug_merged_launches": (C.c_int, []),
     "msq_debug_phase_lookups": (C.c_int, []),
     "msq_debug_tune": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong]),

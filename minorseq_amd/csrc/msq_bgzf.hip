@@ -1,0 +1,497 @@
+// msq_bgzf.hip -- BGZF members inflated on the GPU (the BAM front's first step).
+//
+// The reference reads BAM through pbbam, which inflates BGZF with zlib on the host (src/BamUtils.cpp:56-78 only sees
+// records).  A BGZF file (SAMv1 4.1) is a run of independent gzip members of <= 64 KiB, each one raw DEFLATE stream
+// (RFC 1951) that inflates to exactly its ISIZE -- so the members of a file are the parallel units: ONE WAVE PER
+// MEMBER, 4 waves per workgroup, every member's Huffman tables in its wave's 4.7 KB of LDS.
+//   * The compressed bits are wave-uniform state: a 64-bit bit buffer in scalar registers, refilled 32 bits at a
+//     time from a VGPR that holds the next 256 input bytes (lane i = dword i, read with v_readlane; the chunk after
+//     it is loaded a whole chunk ahead), so the decode loop never waits for global memory.
+//   * Huffman decode: one LDS lookup per symbol in a 2^10 (literal/length) or 2^9 (distance) entry table of
+//     (symbol << 4 | length); longer codes take the canonical first-code / count compare per length.  The tables are
+//     built by the 64 lanes (counts by LDS atomics, canonical order by ballots, every lane fills its 16 entries).
+//   * Literals collect in one VGPR (lane = output offset & 63) and leave as one coalesced 64-byte store;
+//     a match is copied by all lanes at once (source index modulo the distance where the match overlaps itself)
+//     straight in HBM: the wave reads what it has just stored, which the vector memory pipeline keeps in order.
+// Byte work, bit-exact: the test is equality with zlib's output (tests/test_gpu_bgzf.py).  A member that zlib would
+// refuse (invalid block type, stored length check, over-subscribed or incomplete code, repeat without a previous
+// length, missing end-of-block code, invalid symbol, distance too far back, input or output exhausted) is refused
+// here with a status word per member, and the call fails as the host front does ("BGZF block does not inflate to
+// its ISIZE", cpp/msq_bam.hpp).  Every loop is bounded by the member's input bits or its ISIZE (<= 64 KiB, checked
+// on the host), every load is clamped to the padded file image: a crafted member cannot hang or fault the wave.
+#include "msq_internal.h"
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "msq_bam_dev.h"
+
+namespace {
+
+enum : uint32_t {
+    INF_OK = 0,
+    INF_ERR_INPUT = 1,   // the stream runs past the member's payload
+    INF_ERR_BTYPE = 2,   // block type 3
+    INF_ERR_STORED = 3,  // LEN != ~NLEN
+    INF_ERR_COUNTS = 4,  // more than 286 literal/length or 30 distance codes
+    INF_ERR_CODES = 5,   // over-subscribed or incomplete set of code lengths
+    INF_ERR_REPEAT = 6,  // repeat with no previous length, or past the last length
+    INF_ERR_NOEOB = 7,   // no end-of-block code
+    INF_ERR_SYMBOL = 8,  // bits that are no code, or literal/length symbol 286 / 287
+    INF_ERR_DIST = 9,    // distance symbol 30 / 31, or a distance before the member's first byte
+    INF_ERR_OUTPUT = 10, // more than ISIZE bytes
+    INF_ERR_SHORT = 11,  // fewer than ISIZE bytes
+};
+
+constexpr int LIT_BITS = 10, DIST_BITS = 9, CL_BITS = 7;
+
+struct CodeSet {  // a canonical Huffman code, per code length 1..15: first code, number of codes, offset into `sorted`
+    uint16_t first[16], count[16], offs[16];
+};
+
+struct WaveLds {
+    uint16_t lit[1 << LIT_BITS];    // (symbol << 4 | length) by the next LIT_BITS bits; 0: a longer code, or none
+    uint16_t dist[1 << DIST_BITS];
+    uint16_t cl[1 << CL_BITS];      // the code-length alphabet of a dynamic block's header
+    uint16_t sorted_lit[288], sorted_dist[32], sorted_cl[20];  // symbols in canonical order
+    CodeSet cs_lit, cs_dist, cs_cl;
+    uint32_t cnt[16];
+    uint8_t lens[320];              // code lengths: literal/length alphabet, then distance alphabet
+    uint8_t cl_lens[20];
+};
+
+__device__ const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// One wave owns its WaveLds and the LDS executes a wave's operations in order: all that is needed between a lane's
+// write and another lane's read is that the compiler keeps them in order.
+#define WAVE_SYNC()                                           \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+    } while (0)
+
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// The member's compressed bits (see the header).  Everything but cur / nxt is wave-uniform.
+struct BitReader {
+    const uint32_t* words;  // the file image as dwords, zero-padded
+    uint64_t nwords;
+    uint64_t widx;          // the next dword to take
+    uint64_t buf;
+    int cnt;                // valid bits in buf
+    uint32_t cur, nxt;      // lane i: dword (widx & ~63) + i, and the one 64 dwords on
+    int lane;
+
+    __device__ uint32_t load(uint64_t w) const { return w < nwords ? words[w] : 0u; }
+    __device__ void refill()  // afterwards cnt >= 32
+    {
+        if (cnt < 32) {
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(widx & 63));
+            buf |= (uint64_t)w << cnt;
+            cnt += 32;
+            ++widx;
+            if ((widx & 63) == 0) {
+                cur = nxt;
+                nxt = load(widx + 64 + (uint64_t)lane);
+            }
+        }
+    }
+    __device__ void init(uint64_t byte_addr)
+    {
+        widx = byte_addr >> 2;
+        const uint64_t cbase = widx & ~63ull;
+        cur = load(cbase + (uint64_t)lane);
+        nxt = load(cbase + 64 + (uint64_t)lane);
+        buf = 0;
+        cnt = 0;
+        refill();
+        const int skip = (int)(byte_addr & 3) * 8;
+        buf >>= skip;
+        cnt -= skip;
+        refill();
+    }
+    __device__ uint32_t bits(int n)  // n <= 16, cnt >= n
+    {
+        const uint32_t v = (uint32_t)buf & ((1u << n) - 1u);
+        buf >>= n;
+        cnt -= n;
+        return v;
+    }
+    __device__ void drop(int n)
+    {
+        buf >>= n;
+        cnt -= n;
+    }
+    __device__ uint64_t bit_pos() const { return widx * 32 - (uint64_t)cnt; }  // of the next unread bit, from the file's start
+};
+
+// Canonical code of n symbols with code lengths lens[] (0 = unused): per-length tables, symbols in canonical order and
+// the primary lookup table over the next TBITS bits.  zlib's rules (inflate_table): an over-subscribed set is an
+// error, an incomplete one too unless it has no code longer than one bit and the alphabet may be incomplete.
+template <int TBITS>
+__device__ __noinline__ uint32_t build_code(const uint8_t* lens, int n, uint16_t* table, uint16_t* sorted, CodeSet* cs, uint32_t* cnt,
+                               bool may_be_incomplete, int lane)
+{
+    if (lane < 16) cnt[lane] = 0;
+    WAVE_SYNC();
+    for (int s = lane; s < n; s += 64) {
+        const uint32_t L = lens[s];
+        if (L) atomicAdd(&cnt[L], 1u);
+    }
+    WAVE_SYNC();
+    int left = 1, maxlen = 0;
+    bool over = false;
+    uint32_t code = 0, off = 0, my_first = 0, my_offs = 0, my_count = 0;
+    for (int L = 1; L <= 15; ++L) {
+        const uint32_t c = uni(cnt[L]);
+        code <<= 1;  // the first code of length L
+        left = (left << 1) - (int)c;
+        if (left < 0) over = true;
+        if (lane == L) {
+            my_first = code;
+            my_offs = off;
+            my_count = c;
+        }
+        code += c;
+        off += c;
+        if (c) maxlen = L;
+    }
+    if (over) return INF_ERR_CODES;
+    if (left > 0 && !(may_be_incomplete && maxlen <= 1)) return INF_ERR_CODES;
+    if (lane >= 1 && lane < 16) {
+        cs->first[lane] = (uint16_t)my_first;
+        cs->count[lane] = (uint16_t)my_count;
+        cs->offs[lane] = (uint16_t)my_offs;
+    }
+    // symbols in canonical order: by length, then by symbol.  Lane L keeps the next free slot of length L.
+    uint32_t next_slot = my_offs;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int s0 = 0; s0 < n; s0 += 64) {
+        const int s = s0 + lane;
+        const uint32_t myL = s < n ? (uint32_t)lens[s] : 0u;
+        for (int L = 1; L <= 15; ++L) {
+            const uint64_t m = __ballot(myL == (uint32_t)L);
+            if (!m) continue;
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)next_slot, L);
+            if (myL == (uint32_t)L) sorted[base + (uint32_t)__popcll(m & below)] = (uint16_t)s;
+            if (lane == L) next_slot += (uint32_t)__popcll(m);
+        }
+    }
+    WAVE_SYNC();
+    // the primary table: lane l fills entries l, l + 64, ...
+    constexpr int PER = (1 << TBITS) / 64;
+    uint32_t ent[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) ent[k] = 0;
+    for (int L = 1; L <= TBITS; ++L) {
+        const uint32_t c = uni(cs->count[L]);
+        if (!c) continue;
+        const uint32_t f = uni(cs->first[L]), o = uni(cs->offs[L]);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const uint32_t e = (uint32_t)lane + 64u * (uint32_t)k;
+            const uint32_t d = (__brev(e) >> (32 - L)) - f;  // the entry's first L bits as a code (first bit = MSB)
+            if (d < c) ent[k] = (uint32_t)L | ((uint32_t)sorted[o + d] << 4);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) table[lane + 64 * k] = (uint16_t)ent[k];
+    WAVE_SYNC();
+    return INF_OK;
+}
+
+// (symbol << 4 | length) of the code at the head of `buf` (>= 15 bits valid), or 0 when the bits are no code
+template <int TBITS>
+__device__ inline uint32_t decode_sym(uint64_t buf, const uint16_t* table, const uint16_t* sorted, const CodeSet* cs)
+{
+    const uint32_t e = uni(table[(uint32_t)buf & ((1u << TBITS) - 1u)]);
+    if (e & 15u) return e;
+    const uint32_t rev = __brev((uint32_t)buf);
+    for (int L = TBITS + 1; L <= 15; ++L) {
+        const uint32_t c = uni(cs->count[L]);
+        if (!c) continue;
+        const uint32_t d = (rev >> (32 - L)) - uni(cs->first[L]);
+        if (d < c) return (uint32_t)L | (uni(sorted[uni(cs->offs[L]) + d]) << 4);
+    }
+    return 0;
+}
+
+__device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t file_words, const msq_bgzf_member mem,
+                                   uint8_t* __restrict__ out, WaveLds& S, int lane)
+{
+    if (mem.out_len == 0) return INF_OK;  // the end-of-file marker and other empty members: nothing to write
+    const uint8_t* file8 = reinterpret_cast<const uint8_t*>(file32);
+    uint8_t* dst = out + mem.out_off;
+    const uint32_t out_len = mem.out_len;
+    const uint64_t end_bit = (mem.in_off + (uint64_t)mem.in_len) * 8;
+    BitReader br;
+    br.words = file32;
+    br.nwords = file_words;
+    br.lane = lane;
+    br.init(mem.in_off);
+    uint32_t pos = 0, pend_start = 0;  // bytes written; the first byte still in `pend`
+    int pend = 0;                      // lane (p & 63): the literal at output offset p, for pend_start <= p < pos
+    bool fixed_ready = false;
+    auto flush = [&]() {
+        if (pos > pend_start) {
+            const uint32_t base = (pos - 1u) & ~63u, lo = pend_start & 63u, hi = (pos - 1u) & 63u;
+            if ((uint32_t)lane >= lo && (uint32_t)lane <= hi) dst[base + (uint32_t)lane] = (uint8_t)pend;
+            pend_start = pos;
+        }
+    };
+    for (;;) {
+        if (br.bit_pos() + 3 > end_bit) return INF_ERR_INPUT;
+        br.refill();
+        const uint32_t bfinal = br.bits(1), btype = br.bits(2);
+        if (btype == 3) return INF_ERR_BTYPE;
+        if (btype == 0) {
+            br.drop(br.cnt & 7);  // to the byte boundary
+            br.refill();
+            const uint32_t len = br.bits(16), nlen = br.bits(16);
+            if ((len ^ 0xffffu) != nlen) return INF_ERR_STORED;
+            const uint64_t byte = br.bit_pos() >> 3;
+            if ((byte + len) * 8 > end_bit) return INF_ERR_INPUT;
+            if (pos + len > out_len) return INF_ERR_OUTPUT;
+            flush();
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = file8[byte + i];
+            pos += len;
+            pend_start = pos;
+            br.init(byte + len);
+        } else {
+            int n_lit, n_dist;
+            if (btype == 1) {
+                n_lit = 288;
+                n_dist = 32;
+                if (!fixed_ready) {
+                    for (int s = lane; s < 320; s += 64) S.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+                    WAVE_SYNC();
+                }
+            } else {
+                br.refill();
+                n_lit = (int)br.bits(5) + 257;
+                n_dist = (int)br.bits(5) + 1;
+                const int n_cl = (int)br.bits(4) + 4;
+                if (n_lit > 286 || n_dist > 30) return INF_ERR_COUNTS;
+                if (lane < 19) S.cl_lens[lane] = 0;
+                WAVE_SYNC();
+                for (int i = 0; i < n_cl; ++i) {
+                    br.refill();
+                    const uint32_t v = br.bits(3);
+                    if (lane == 0) S.cl_lens[kClOrder[i]] = (uint8_t)v;
+                }
+                WAVE_SYNC();
+                if (const uint32_t e = build_code<CL_BITS>(S.cl_lens, 19, S.cl, S.sorted_cl, &S.cs_cl, S.cnt, false, lane)) return e;
+                const int total = n_lit + n_dist;
+                int i = 0;
+                uint32_t prev = 0;
+                while (i < total) {
+                    if (br.bit_pos() > end_bit) return INF_ERR_INPUT;
+                    br.refill();
+                    const uint32_t e = decode_sym<CL_BITS>(br.buf, S.cl, S.sorted_cl, &S.cs_cl);
+                    if (!e) return INF_ERR_SYMBOL;
+                    br.drop((int)(e & 15u));
+                    const uint32_t sym = e >> 4;
+                    if (sym < 16) {
+                        if (lane == 0) S.lens[i] = (uint8_t)sym;
+                        prev = sym;
+                        ++i;
+                        continue;
+                    }
+                    uint32_t v = 0;
+                    int rep;
+                    if (sym == 16) {
+                        if (i == 0) return INF_ERR_REPEAT;
+                        v = prev;
+                        rep = 3 + (int)br.bits(2);
+                    } else if (sym == 17) {
+                        rep = 3 + (int)br.bits(3);
+                        prev = 0;
+                    } else {
+                        rep = 11 + (int)br.bits(7);
+                        prev = 0;
+                    }
+                    if (i + rep > total) return INF_ERR_REPEAT;
+                    for (int k = lane; k < rep; k += 64) S.lens[i + k] = (uint8_t)v;
+                    i += rep;
+                }
+                WAVE_SYNC();
+                if (uni(S.lens[256]) == 0) return INF_ERR_NOEOB;
+            }
+            if (btype == 2 || !fixed_ready) {
+                if (const uint32_t e = build_code<LIT_BITS>(S.lens, n_lit, S.lit, S.sorted_lit, &S.cs_lit, S.cnt, true, lane)) return e;
+                if (const uint32_t e = build_code<DIST_BITS>(S.lens + n_lit, n_dist, S.dist, S.sorted_dist, &S.cs_dist, S.cnt, true, lane)) return e;
+                fixed_ready = btype == 1;
+            }
+            for (;;) {
+                br.refill();
+                const uint32_t e = decode_sym<LIT_BITS>(br.buf, S.lit, S.sorted_lit, &S.cs_lit);
+                if (!e) return INF_ERR_SYMBOL;
+                br.drop((int)(e & 15u));
+                const uint32_t sym = e >> 4;
+                if (sym < 256) {
+                    if (pos >= out_len) return INF_ERR_OUTPUT;
+                    pend = (uint32_t)lane == (pos & 63u) ? (int)sym : pend;
+                    ++pos;
+                    if ((pos & 63u) == 0) flush();
+                    continue;
+                }
+                if (sym == 256) break;
+                if (sym > 285) return INF_ERR_SYMBOL;
+                uint32_t len;
+                if (sym < 265) {
+                    len = sym - 254;
+                } else if (sym == 285) {
+                    len = 258;
+                } else {
+                    const int xb = (int)((sym - 261) >> 2);
+                    len = ((4u + ((sym - 265) & 3u)) << xb) + 3u + br.bits(xb);
+                }
+                br.refill();
+                const uint32_t de = decode_sym<DIST_BITS>(br.buf, S.dist, S.sorted_dist, &S.cs_dist);
+                if (!de) return INF_ERR_SYMBOL;
+                br.drop((int)(de & 15u));
+                const uint32_t dsym = de >> 4;
+                if (dsym > 29) return INF_ERR_DIST;
+                uint32_t dist;
+                if (dsym < 4) {
+                    dist = dsym + 1;
+                } else {
+                    const int xb = (int)(dsym >> 1) - 1;
+                    dist = ((2u + (dsym & 1u)) << xb) + 1u + br.bits(xb);
+                }
+                if (dist > pos) return INF_ERR_DIST;
+                if (pos + len > out_len) return INF_ERR_OUTPUT;
+                flush();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the copy reads what this wave has stored
+                const uint8_t* src = dst + (pos - dist);
+                if (dist >= len) {
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = src[i];
+                } else {  // the match overlaps itself: its bytes repeat with period dist, all of them already written
+                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = src[i % dist];
+                }
+                pos += len;
+                pend_start = pos;
+                if (br.bit_pos() > end_bit) return INF_ERR_INPUT;
+            }
+            if (br.bit_pos() > end_bit) return INF_ERR_INPUT;
+        }
+        if (bfinal) break;
+    }
+    flush();
+    if (pos != out_len) return INF_ERR_SHORT;
+    return INF_OK;
+}
+
+__global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint32_t* __restrict__ file32, uint64_t file_words,
+                                                           const msq_bgzf_member* __restrict__ members, uint32_t n_members,
+                                                           uint8_t* __restrict__ out, uint32_t* __restrict__ status)
+{
+    __shared__ WaveLds lds[4];
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    const uint32_t m = blockIdx.x * 4u + wave;
+    if (m >= n_members) return;
+    const uint32_t err = inflate_member(file32, file_words, members[m], out, lds[wave], lane);
+    if (lane == 0) status[m] = err;
+}
+
+}  // namespace
+
+static void free_bam_dev(msq_bam_dev* b)
+{
+    if (!b) return;
+    for (void* p : {(void*)b->d_data, (void*)b->d_rec_off, (void*)b->d_rec, (void*)b->d_kept})
+        if (p) (void)hipFree(p);
+    delete b;
+}
+
+extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64_t file_bytes, const msq_bgzf_member* members,
+                                       uint64_t n_members, msq_bam_dev** out)
+{
+    if (!ctx || !out) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_inflate_device: NULL argument");
+    *out = nullptr;
+    if ((file_bytes && !file) || (n_members && !members)) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_inflate_device: NULL array");
+    if (n_members > 0xfffffff0ull) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_inflate_device: too many members");
+    uint64_t total = 0;
+    for (uint64_t m = 0; m < n_members; ++m) {
+        const msq_bgzf_member& k = members[m];
+        if (k.in_off > file_bytes || k.in_len > file_bytes - k.in_off) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_inflate_device: member %llu lies outside the file", (unsigned long long)m);
+        // SAMv1 4.1: a BGZF block inflates to at most 64 KiB; this bounds every loop of the kernel
+        if (k.out_len > 65536u) return msq_fail(MSQ_ERR_DATA, "BGZF block %llu claims %u bytes (more than 64 KiB)", (unsigned long long)m, k.out_len);
+        if (k.out_off != total) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_inflate_device: member %llu does not follow its predecessor in the output", (unsigned long long)m);
+        total += k.out_len;
+    }
+    MSQ_HIP(hipSetDevice(ctx->device));
+    msq_bam_dev* b = new (std::nothrow) msq_bam_dev;
+    if (!b) return msq_fail(MSQ_ERR_NOMEM, "msq_bgzf_inflate_device: out of memory");
+    void *d_file = nullptr, *d_members = nullptr, *d_status = nullptr;
+    auto fail = [&](int code, const char* what, hipError_t e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void* p : {d_file, d_members, d_status})
+            if (p) (void)hipFree(p);
+        free_bam_dev(b);
+        return msq_fail(code, "msq_bgzf_inflate_device: %s: %s", what, hipGetErrorString(e));
+    };
+    const uint64_t file_padded = ((file_bytes + 3) & ~3ull) + 1024;  // the bit reader looks two chunks ahead
+    const uint64_t data_padded = total + MSQ_BAM_DATA_PAD;
+    hipError_t e = hipMalloc(&d_file, file_padded);
+    if (e == hipSuccess) e = hipMalloc(&d_members, std::max<uint64_t>(n_members, 1) * sizeof(msq_bgzf_member));
+    if (e == hipSuccess) e = hipMalloc(&d_status, std::max<uint64_t>(n_members, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&b->d_data, data_padded);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "hipMalloc", e);
+    b->data_bytes = total;
+    e = hipMemsetAsync((char*)d_file + (file_bytes & ~3ull), 0, file_padded - (file_bytes & ~3ull), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_data + total, 0, MSQ_BAM_DATA_PAD, ctx->stream);
+    if (e == hipSuccess && file_bytes) e = hipMemcpyAsync(d_file, file, file_bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_members) e = hipMemcpyAsync(d_members, members, n_members * sizeof(msq_bgzf_member), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_status, 0xFF, std::max<uint64_t>(n_members, 1) * 4, ctx->stream);
+    if (e != hipSuccess) return fail(MSQ_ERR_HIP, "upload", e);
+    std::vector<uint32_t> status;
+    try {
+        status.resize(n_members);
+    } catch (const std::bad_alloc&) {
+        return fail(MSQ_ERR_NOMEM, "status", hipErrorOutOfMemory);
+    }
+    if (n_members) {
+        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((n_members + 3) / 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_file,
+                           file_padded / 4, (const msq_bgzf_member*)d_members, (uint32_t)n_members, b->d_data, (uint32_t*)d_status);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(status.data(), d_status, n_members * 4, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(MSQ_ERR_HIP, "inflate kernel", e);
+    for (void* p : {d_file, d_members, d_status}) (void)hipFree(p);
+    d_file = d_members = d_status = nullptr;
+    for (uint64_t m = 0; m < n_members; ++m)
+        if (status[m] != INF_OK) {
+            free_bam_dev(b);
+            // std::runtime_error("BGZF block does not inflate to its ISIZE") of the host front (cpp/msq_bam.hpp)
+            return msq_fail(MSQ_ERR_DATA, "BGZF block does not inflate to its ISIZE (member %llu, code %u)", (unsigned long long)m, status[m]);
+        }
+    *out = b;
+    return MSQ_OK;
+}
+
+extern "C" uint64_t msq_bam_dev_bytes(const msq_bam_dev* b) { return b ? b->data_bytes : 0; }
+
+extern "C" int msq_bam_dev_read(msq_ctx* ctx, const msq_bam_dev* b, uint64_t off, uint64_t len, void* host_dst)
+{
+    if (!ctx || !b || (len && !host_dst)) return msq_fail(MSQ_ERR_ARG, "msq_bam_dev_read: NULL argument");
+    if (off > b->data_bytes || len > b->data_bytes - off) return msq_fail(MSQ_ERR_ARG, "msq_bam_dev_read: range outside the stream");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    if (len) MSQ_HIP(hipMemcpyAsync(host_dst, b->d_data + off, len, hipMemcpyDeviceToHost, ctx->stream));
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));
+    return MSQ_OK;
+}
+
+extern "C" int msq_bam_dev_free(msq_ctx* ctx, msq_bam_dev* b)
+{
+    if (!b) return MSQ_OK;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    free_bam_dev(b);
+    return MSQ_OK;
+}

@@ -59,6 +59,7 @@ struct msq_ctx {
     bool no_merge = false;
     int64_t carrier_min_batches = -1;  // < 0: the kernel's default
     bool no_haps = false;              // MSQ_NO_HAPS / MSQ_TUNE_NO_HAPS: msq_reads_align makes no haplotype groups
+    uint64_t bam_segment_bytes = 16384;  // msq_bam_index_device: the stream is searched for record starts in segments of this size
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when `lds` exceeds what was last set for this kernel on this device
@@ -94,4 +95,9 @@ int msq_noalloc_init(msq_ctx* ctx);
 int msq_packed_dev_index(msq_ctx* ctx, msq_packed_dev* d);
 // The checks every entry point that streams packed reads shares: read arrays present, bit planes and QV planes
 // 16-byte aligned (the kernels load uint4), thresholds in -1..255 (qv_pass_mask's byte arithmetic).
+// The device packer over bytes that are already in HBM (msq_bam_pack_device): d_compact holds one translated byte per
+// base (msq_pack_reads_device_fill_compact's staging format), read r at base_off[r]; presence as a fill callback reports it.
+int msq_pack_compact_resident(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end, const uint64_t* base_off,
+                              const uint64_t* d_base_off, const uint8_t* d_compact, uint32_t presence, uint32_t pack_flags,
+                              const msq_qv_thresholds* thr, msq_packed_dev** out);
 int msq_validate_reads(const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, const char* who);

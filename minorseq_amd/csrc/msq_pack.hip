@@ -663,6 +663,83 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
     return MSQ_OK;
 }
 
+// The device packer over translated bytes that are already in HBM (the BAM front on the device, msq_bam_pack_device):
+// the tail of pack_reads_device_impl without staging -- read tables up, one pack_groups_kernel over all groups, flags,
+// column index.  Same packed bytes as msq_pack_reads_device_fill_compact on the same bytes.
+int msq_pack_compact_resident(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end, const uint64_t* base_off,
+                              const uint64_t* d_base_off, const uint8_t* d_compact, uint32_t presence, uint32_t pack_flags,
+                              const msq_qv_thresholds* thr_in, msq_packed_dev** out)
+{
+    *out = nullptr;
+    if (pack_flags & ~MSQ_PACK_PLAIN) return msq_fail(MSQ_ERR_ARG, "msq_bam_pack_device: unknown pack flag");
+    const int plain = (pack_flags & MSQ_PACK_PLAIN) ? 1 : 0;
+    const msq_qv_thresholds thr = *thr_in;
+    std::vector<uint64_t> group_off;
+    try {
+        group_off.resize(n_reads + 1);
+    } catch (const std::bad_alloc&) {
+        return msq_fail(MSQ_ERR_NOMEM, "msq_bam_pack_device: out of memory");
+    }
+    group_off[0] = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) group_off[r + 1] = group_off[r] + (base_off[r + 1] - base_off[r] + 31) / 32;
+    const uint64_t n_groups = group_off[n_reads];
+    void* scratch = nullptr;
+    if (int rc = msq_scratch(ctx, 256, &scratch)) return rc;
+    unsigned long long* d_errword = (unsigned long long*)scratch;
+    uint32_t* d_flags = (uint32_t*)((char*)scratch + 8);
+    MSQ_HIP(hipMemsetAsync(scratch, 0xFF, 8, ctx->stream));
+    MSQ_HIP(hipMemsetAsync(d_flags, 0, 8, ctx->stream));
+    msq_packed_dev* d = new (std::nothrow) msq_packed_dev;
+    if (!d) return msq_fail(MSQ_ERR_NOMEM, "msq_bam_pack_device: out of memory");
+    auto fail = [&](int code, const char* what, hipError_t e) {
+        (void)hipStreamSynchronize(ctx->stream);
+        free_packed_dev(d);
+        return msq_fail(code, "msq_bam_pack_device: %s: %s", what, hipGetErrorString(e));
+    };
+    const void* src[4] = {ref_start, ref_end, group_off.data(), nullptr};
+    const size_t bytes[4] = {n_reads * 4, n_reads * 4, (n_reads + 1) * 8, n_groups * 16};
+    for (int k = 0; k < 4; ++k) {
+        hipError_t e = hipMalloc(&d->ptrs[k], bytes[k] ? bytes[k] : 16);
+        if (e == hipSuccess && bytes[k] && src[k]) e = hipMemcpyAsync(d->ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "read tables", e);
+    }
+    if (n_groups) {
+        const uint64_t blocks = (n_groups + 7) / 8;  // 4 waves x 2 groups
+        if (blocks > 0x7fffffffull) return fail(MSQ_ERR_ARG, "too many groups for one launch", hipErrorInvalidValue);
+        hipLaunchKernelGGL(pack_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint64_t*>(d_compact), (uint64_t)0,
+                           d_base_off, (const uint64_t*)d->ptrs[2], (uint64_t)0, n_reads, (uint64_t)0, n_groups, (uint4*)d->ptrs[3], (uint8_t*)nullptr,
+                           (uint8_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, d_errword, d_flags, plain, 1, thr, 1);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(MSQ_ERR_HIP, "pack kernel", e);
+    }
+    uint64_t res[2] = {~0ull, 0};
+    {
+        hipError_t e = hipMemcpyAsync(res, scratch, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(MSQ_ERR_HIP, "result copy", e);
+    }
+    msq_packed_reads& v = d->view;
+    v.n_reads = n_reads;
+    v.n_groups = n_groups;
+    v.ref_start = (const int32_t*)d->ptrs[0];
+    v.ref_end = (const int32_t*)d->ptrs[1];
+    v.group_off = (const uint64_t*)d->ptrs[2];
+    v.bop = (const uint32_t*)d->ptrs[3];
+    v.qual = v.delqv = v.subqv = v.insqv = nullptr;
+    v.flags = ((uint32_t)res[1] & (MSQ_READS_HAS_EXOTIC | MSQ_READS_INS_EXOTIC)) | (plain ? MSQ_READS_PAD_MARKED : MSQ_READS_NORMALIZED);
+    const bool has_q = (presence & 1u) != 0, has_r = (presence & 2u) != 0;
+    if ((thr.qual >= 0 && has_q) || (has_r && (thr.del >= 0 || thr.sub >= 0 || thr.ins >= 0))) v.flags |= MSQ_READS_QV_BAKED;
+    v.align_origin = 0;
+    v.gcol = nullptr;
+    if (int rc2 = msq_packed_dev_index(ctx, d)) {
+        (void)hipStreamSynchronize(ctx->stream);
+        free_packed_dev(d);
+        return rc2;
+    }
+    *out = d;
+    return MSQ_OK;
+}
+
 extern "C" int msq_pack_reads_device(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end,
                                      const msq_array_base* const* bases, const int64_t* n_bases, uint32_t pack_flags,
                                      int threads, int64_t chunk_bases, msq_packed_dev** out)
