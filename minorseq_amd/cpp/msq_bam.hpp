@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -85,6 +86,7 @@ public:
     }
     size_t size() const { return n_; }
     const uint8_t& operator[](size_t i) const { return p_[i]; }
+    const uint8_t* data() const { return p_; }
 
 private:
     const uint8_t* p_ = nullptr;
@@ -161,8 +163,9 @@ struct Deflater {
     }
 };
 
-// BGZF (SAMv1 4.1): gzip members with FEXTRA holding the subfield 'B','C',2,BSIZE; inflate them in parallel.
-inline Bytes InflateBgzf(const MappedFile& file, unsigned threads)
+// BGZF (SAMv1 4.1): gzip members with FEXTRA holding the subfield 'B','C',2,BSIZE.  Where the members are and what
+// they inflate to; *total = the inflated stream's length.
+inline std::vector<BgzfBlock> ScanBgzf(const MappedFile& file, size_t* total)
 {
     std::vector<BgzfBlock> blocks;
     size_t off = 0, out = 0;
@@ -188,6 +191,15 @@ inline Bytes InflateBgzf(const MappedFile& file, unsigned threads)
         out += isize;
         off += bsize;
     }
+    *total = out;
+    return blocks;
+}
+
+// ... and inflated in parallel on host threads.
+inline Bytes InflateBgzf(const MappedFile& file, unsigned threads)
+{
+    size_t out = 0;
+    const std::vector<BgzfBlock> blocks = ScanBgzf(file, &out);
     Bytes data(out);
     const Deflater* fast = Deflater::Get();
     auto work = [&](size_t first, size_t step) {
@@ -429,6 +441,181 @@ struct BamUtils
             timings->bam_bytes = loaded->data.size();
             timings->records = loaded->n_records;
             timings->kept = n;
+        }
+        return source;
+    }
+
+    /// The same reads with the file decoded ON THE GPU (csrc/msq_bgzf.hip, msq_bamdev.hip): the compressed file image
+    /// crosses PCIe once, BGZF members are inflated one wave each, the record chain, the filters, the reference intervals
+    /// and base counts are worked out there, and MSAByRow packs the reads without the host (ReadSource::packDevice ->
+    /// msq_bam_pack_device); only the per-record table and the names come back.  A file the device front declines
+    /// (MSQ_ERR_DATA: a block that does not inflate, a malformed record, a cigar that some later step throws on) goes
+    /// through BamToReadSource instead, which reports the error as before -- so the two are interchangeable.
+    /// fill / fillCompact (literal bases for insertion strings beyond the packed form) load the file on the host on
+    /// first use.  `usedDevice`, if given, says which front produced the source.
+    static Data::ReadSource BamToReadSourceDevice(const std::string& filePath, int regionStart, int regionEnd,
+                                                  unsigned threads = std::thread::hardware_concurrency(), BamTimings* timings = nullptr,
+                                                  std::vector<std::string>* chemistries = nullptr, bool* usedDevice = nullptr)
+    {
+        using namespace detail;
+        using Clock = std::chrono::steady_clock;
+        auto secs = [](Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        if (usedDevice) *usedDevice = false;
+        if (threads == 0) threads = 1;
+        const int regionStart0 = std::max(regionStart - 1, 0), regionEnd0 = std::max(regionEnd - 1, 0);
+        msq_ctx* ctx = Msq::Context();
+        struct DevBam  // the file in HBM, freed with the last copy of the source
+        {
+            msq_bam_dev* bam = nullptr;
+            ~DevBam() { if (bam) msq_bam_dev_free(Msq::Context(), bam); }
+        };
+        const auto dev = std::make_shared<DevBam>();
+        const auto t0 = Clock::now();
+        size_t fileBytes = 0, bamBytes = 0;
+        uint64_t nRecords = 0, nKept = 0;
+        std::vector<std::pair<std::string, std::string>> readGroups;
+        Clock::time_point t1, t2;
+        {
+            const MappedFile file(filePath);
+            fileBytes = file.size();
+            const std::vector<BgzfBlock> blocks = ScanBgzf(file, &bamBytes);
+            std::vector<msq_bgzf_member> members(blocks.size());
+            for (size_t b = 0; b < blocks.size(); ++b)
+                members[b] = msq_bgzf_member{(uint64_t)blocks[b].in_off, (uint64_t)blocks[b].out_off, (uint32_t)blocks[b].in_len, (uint32_t)blocks[b].out_len};
+            t1 = Clock::now();
+            const int rc = msq_bgzf_inflate_device(ctx, file.data(), file.size(), members.data(), members.size(), &dev->bam);
+            if (rc == MSQ_ERR_DATA) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);
+            Msq::Check(rc);
+            t2 = Clock::now();
+        }
+        // the BAM header comes back (text with the read groups, reference names): the first record sits behind it
+        uint64_t first = 0;
+        int32_t nRef = 0;
+        {
+            std::vector<uint8_t> head(std::min<uint64_t>(bamBytes, 1 << 16));
+            auto need = [&](uint64_t n) {  // the first n bytes of the stream, or the host front's refusal
+                if (n > bamBytes) return false;
+                if (n > head.size()) head.resize(std::min<uint64_t>(bamBytes, std::max<uint64_t>(n, head.size() * 2)));
+                return true;
+            };
+            uint64_t have = 0;
+            auto fetch = [&]() {
+                if (have < head.size()) {
+                    Msq::Check(msq_bam_dev_read(ctx, dev->bam, have, head.size() - have, head.data() + have));
+                    have = head.size();
+                }
+            };
+            fetch();
+            bool ok = need(12) && std::memcmp(head.data(), "BAM\1", 4) == 0;
+            uint64_t off = 4;
+            size_t lText = 0;
+            if (ok) {
+                lText = U32(&head[off]);
+                ok = need(off + 4 + lText + 4);
+            }
+            if (ok) {
+                fetch();
+                readGroups = ReadGroupChemistries(std::string(reinterpret_cast<const char*>(&head[off + 4]), lText));
+                off += 4 + lText;
+                const size_t n = U32(&head[off]);
+                off += 4;
+                for (size_t r = 0; ok && r < n; ++r) {
+                    ok = need(off + 4);
+                    if (!ok) break;
+                    fetch();
+                    const size_t lName = U32(&head[off]);
+                    ok = lName <= bamBytes && need(off + 4 + lName + 4);
+                    off += 4 + lName + 4;
+                }
+                ok = ok && n <= 0x7fffffffu;
+                nRef = (int32_t)n;
+                first = off;
+            }
+            if (!ok) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);  // "not a BAM file" / "truncated BAM header"
+        }
+        {
+            const int rc = msq_bam_index_device(ctx, dev->bam, first, nRef, regionStart0, regionEnd0, &nRecords, &nKept);
+            if (rc == MSQ_ERR_DATA) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);
+            Msq::Check(rc);
+        }
+        std::vector<msq_bam_record> kept(nKept);
+        Msq::Check(msq_bam_records(ctx, dev->bam, kept.data()));
+        uint64_t nameBytes = 0;
+        for (const auto& k : kept) nameBytes += k.l_read_name;
+        std::vector<char> nameBuf(nameBytes + 1);
+        Msq::Check(msq_bam_names(ctx, dev->bam, nameBuf.data(), nameBytes));
+        Data::ReadSource source;
+        source.names.resize(nKept);
+        source.referenceStart.resize(nKept);
+        source.referenceEnd.resize(nKept);
+        source.numBases.resize(nKept);
+        uint64_t at = 0;
+        std::vector<std::string> chems;
+        for (size_t r = 0; r < nKept; ++r) {
+            const msq_bam_record& k = kept[r];
+            if (k.rg_len == 254) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);  // a read group id beyond the table's 16 chars
+            source.names[r] = nameBuf.data() + at;  // up to the name's NUL
+            at += k.l_read_name;
+            source.referenceStart[r] = std::max(k.ref_start, (int32_t)regionStart0);
+            source.referenceEnd[r] = std::min(k.ref_end, (int32_t)regionEnd0);
+            source.numBases[r] = k.n_bases;
+            if (chemistries) {
+                std::string chem;
+                if (k.rg_len != 255) {
+                    const std::string id(k.rg, k.rg_len);
+                    for (const auto& g : readGroups)
+                        if (g.first == id) chem = g.second;
+                }
+                if (std::find(chems.begin(), chems.end(), chem) == chems.end()) chems.push_back(std::move(chem));
+            }
+        }
+        if (chemistries)
+            for (const auto& chem : chems)
+                if (std::find(chemistries->begin(), chemistries->end(), chem) == chemistries->end()) chemistries->push_back(chem);
+        source.packDevice = [dev](uint32_t packFlags, size_t firstRead, size_t count, const msq_qv_thresholds& thr, msq_packed_dev** out) {
+            return msq_bam_pack_device(Msq::Context(), dev->bam, firstRead, count, packFlags, &thr, out);
+        };
+        // literal bases of a read (rare: insertion strings the packed form cannot hold): the host front, loaded on first use
+        struct Lazy
+        {
+            std::string path;
+            int regionStart, regionEnd;
+            unsigned threads;
+            std::mutex mutex;
+            std::shared_ptr<const Loaded> loaded;
+            const Loaded& Get()
+            {
+                std::lock_guard<std::mutex> lock(mutex);
+                if (!loaded) loaded = std::make_shared<const Loaded>(Load(path, regionStart, regionEnd, threads));
+                return *loaded;
+            }
+        };
+        const auto lazy = std::make_shared<Lazy>();
+        lazy->path = filePath;
+        lazy->regionStart = regionStart0;
+        lazy->regionEnd = regionEnd0;
+        lazy->threads = threads;
+        source.fill = [lazy](uint64_t read, Data::ArrayBase* dst) {
+            const Loaded& L = lazy->Get();
+            const Kept& k = L.kept[read];
+            DecodeBases(&L.data[k.off], k.block_size, k.ref_start, k.ref_end, lazy->regionStart, lazy->regionEnd, lazy->path,
+                        [&dst](const Data::ArrayBase& b) { *dst++ = b; });
+        };
+        source.fillCompact = [lazy](uint64_t read, uint8_t* dst, const msq_qv_thresholds& thr, uint32_t* presence) {
+            const Loaded& L = lazy->Get();
+            const Kept& k = L.kept[read];
+            return DecodeBasesCompact(&L.data[k.off], k.block_size, k.ref_start, k.ref_end, lazy->regionStart, lazy->regionEnd, lazy->path, thr, dst, presence);
+        };
+        if (usedDevice) *usedDevice = true;
+        if (timings) {
+            timings->read = secs(t0, t1);
+            timings->inflate = secs(t1, t2);
+            timings->index = secs(t2, Clock::now());
+            timings->parse = 0;
+            timings->file_bytes = fileBytes;
+            timings->bam_bytes = bamBytes;
+            timings->records = nRecords;
+            timings->kept = nKept;
         }
         return source;
     }

@@ -267,6 +267,10 @@ struct ReadSource
     /// (index of the first base with an unknown cigar) << 8 | that cigar.  A producer that decodes and translates in
     /// one go (the BAM front) saves the 8-byte records; used when present.
     std::function<int64_t(uint64_t read, uint8_t* dst, const msq_qv_thresholds& thr, uint32_t* presence)> fillCompact;
+    /// Optional: the reads are in HBM already (the BAM front on the device, BamUtils::BamToReadSourceDevice): packs reads
+    /// [first, first + count) there, thresholds applied (msq_bam_pack_device); used when present, and fill / fillCompact
+    /// then only serve the rare look-ups of literal bases.
+    std::function<int(uint32_t packFlags, size_t first, size_t count, const msq_qv_thresholds& thr, msq_packed_dev** dev)> packDevice;
 };
 
 class MSAByRow  // include/pacbio/data/MSA.h:59-93
@@ -594,6 +598,10 @@ private:
     static int PackSource(const ReadSource& source, uint32_t packFlags, size_t first, size_t count, const msq_qv_thresholds& thr,
                           msq_packed_dev** dev, std::exception_ptr* thrown)
     {
+        if (source.packDevice) {  // decoded where they are
+            *thrown = nullptr;
+            return source.packDevice(packFlags, first, count, thr, dev);
+        }
         struct Relay  // the callback crosses a C boundary: keep the first exception and hand it back afterwards
         {
             const ReadSource* source;

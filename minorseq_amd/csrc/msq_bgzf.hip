@@ -10,8 +10,10 @@
 //   * Huffman decode: one LDS lookup per symbol in a 2^10 (literal/length) or 2^9 (distance) entry table of
 //     (symbol << 4 | length); longer codes take the canonical first-code / count compare per length.  The tables are
 //     built by the 64 lanes (counts by LDS atomics, canonical order by ballots, every lane fills its 16 entries).
-//   * Literals collect in one VGPR (lane = output offset & 63) and leave as one coalesced 64-byte store;
-//     a match is copied by all lanes at once (source index modulo the distance where the match overlaps itself)
+//   * Literals are decoded speculatively: lane k looks up the code that would start k bits into the bit buffer, the
+//     wave walks the chain of real code starts through those 64 entries with v_readlane, and the window's literals
+//     leave in one store (one LDS access and ~60 instructions per ~5 literals; a kernel of this shape is bound by the
+//     CU's instruction issue, one wave-instruction per cycle, not by memory).  A match is copied by all lanes at once (source index modulo the distance where the match overlaps itself)
 //     straight in HBM: the wave reads what it has just stored, which the vector memory pipeline keeps in order.
 // Byte work, bit-exact: the test is equality with zlib's output (tests/test_gpu_bgzf.py).  A member that zlib would
 // refuse (invalid block type, stored length check, over-subscribed or incomplete code, repeat without a previous
@@ -45,13 +47,16 @@ enum : uint32_t {
 };
 
 constexpr int LIT_BITS = 10, DIST_BITS = 9, CL_BITS = 7;
+// a primary-table entry is (symbol << 4 | code length), with bit 15 set on everything that is not a literal: one compare
+// keeps the literal loop going
+constexpr uint32_t kNotLiteral = 0x8000u;
 
 struct CodeSet {  // a canonical Huffman code, per code length 1..15: first code, number of codes, offset into `sorted`
     uint16_t first[16], count[16], offs[16];
 };
 
 struct WaveLds {
-    uint16_t lit[1 << LIT_BITS];    // (symbol << 4 | length) by the next LIT_BITS bits; 0: a longer code, or none
+    uint16_t lit[1 << LIT_BITS];    // (symbol << 4 | length | kNotLiteral) by the next LIT_BITS bits; length 0: a longer code, or none
     uint16_t dist[1 << DIST_BITS];
     uint16_t cl[1 << CL_BITS];      // the code-length alphabet of a dynamic block's header
     uint16_t sorted_lit[288], sorted_dist[32], sorted_cl[20];  // symbols in canonical order
@@ -83,10 +88,12 @@ struct BitReader {
     uint32_t cur, nxt;      // lane i: dword (widx & ~63) + i, and the one 64 dwords on
     int lane;
 
-    __device__ uint32_t load(uint64_t w) const { return w < nwords ? words[w] : 0u; }
-    __device__ void refill()  // afterwards cnt >= 32
+    // clamped, not predicated: the last dwords of the image are zero padding, and a load that always happens can land
+    // in the register that carries it to its use 64 refills later (no wait where it is issued)
+    __device__ uint32_t load(uint64_t w) const { return words[w < nwords ? w : nwords - 1]; }
+    __device__ void refill()  // afterwards cnt > 32
     {
-        if (cnt < 32) {
+        if (cnt <= 32) {
             const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(widx & 63));
             buf |= (uint64_t)w << cnt;
             cnt += 32;
@@ -183,7 +190,7 @@ __device__ __noinline__ uint32_t build_code(const uint8_t* lens, int n, uint16_t
     constexpr int PER = (1 << TBITS) / 64;
     uint32_t ent[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) ent[k] = 0;
+    for (int k = 0; k < PER; ++k) ent[k] = kNotLiteral;  // a longer code, or none
     for (int L = 1; L <= TBITS; ++L) {
         const uint32_t c = uni(cs->count[L]);
         if (!c) continue;
@@ -192,7 +199,10 @@ __device__ __noinline__ uint32_t build_code(const uint8_t* lens, int n, uint16_t
         for (int k = 0; k < PER; ++k) {
             const uint32_t e = (uint32_t)lane + 64u * (uint32_t)k;
             const uint32_t d = (__brev(e) >> (32 - L)) - f;  // the entry's first L bits as a code (first bit = MSB)
-            if (d < c) ent[k] = (uint32_t)L | ((uint32_t)sorted[o + d] << 4);
+            if (d < c) {
+                const uint32_t sym = sorted[o + d];
+                ent[k] = (uint32_t)L | (sym << 4) | (sym >= 256 ? kNotLiteral : 0u);
+            }
         }
     }
 #pragma unroll
@@ -201,13 +211,12 @@ __device__ __noinline__ uint32_t build_code(const uint8_t* lens, int n, uint16_t
     return INF_OK;
 }
 
-// (symbol << 4 | length) of the code at the head of `buf` (>= 15 bits valid), or 0 when the bits are no code
+// the code at the head of `buf` is longer than the primary table's bits: the canonical compare per length.
+// (symbol << 4 | length), or 0 when the bits are no code
 template <int TBITS>
-__device__ inline uint32_t decode_sym(uint64_t buf, const uint16_t* table, const uint16_t* sorted, const CodeSet* cs)
+__device__ __noinline__ uint32_t long_sym(uint32_t head, const uint16_t* sorted, const CodeSet* cs)
 {
-    const uint32_t e = uni(table[(uint32_t)buf & ((1u << TBITS) - 1u)]);
-    if (e & 15u) return e;
-    const uint32_t rev = __brev((uint32_t)buf);
+    const uint32_t rev = __brev(head);
     for (int L = TBITS + 1; L <= 15; ++L) {
         const uint32_t c = uni(cs->count[L]);
         if (!c) continue;
@@ -215,6 +224,15 @@ __device__ inline uint32_t decode_sym(uint64_t buf, const uint16_t* table, const
         if (d < c) return (uint32_t)L | (uni(sorted[uni(cs->offs[L]) + d]) << 4);
     }
     return 0;
+}
+
+// (symbol << 4 | length) of the code at the head of `buf` (>= 15 bits valid), or 0 when the bits are no code
+template <int TBITS>
+__device__ inline uint32_t decode_sym(uint64_t buf, const uint16_t* table, const uint16_t* sorted, const CodeSet* cs)
+{
+    const uint32_t e = uni(table[(uint32_t)buf & ((1u << TBITS) - 1u)]) & ~kNotLiteral;
+    if (e & 15u) return e;
+    return uni(long_sym<TBITS>((uint32_t)buf, sorted, cs));
 }
 
 __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t file_words, const msq_bgzf_member mem,
@@ -230,16 +248,9 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
     br.nwords = file_words;
     br.lane = lane;
     br.init(mem.in_off);
-    uint32_t pos = 0, pend_start = 0;  // bytes written; the first byte still in `pend`
-    int pend = 0;                      // lane (p & 63): the literal at output offset p, for pend_start <= p < pos
+    uint32_t pos = 0;  // bytes written
     bool fixed_ready = false;
-    auto flush = [&]() {
-        if (pos > pend_start) {
-            const uint32_t base = (pos - 1u) & ~63u, lo = pend_start & 63u, hi = (pos - 1u) & 63u;
-            if ((uint32_t)lane >= lo && (uint32_t)lane <= hi) dst[base + (uint32_t)lane] = (uint8_t)pend;
-            pend_start = pos;
-        }
-    };
+    const uint64_t below = (1ull << lane) - 1ull;
     for (;;) {
         if (br.bit_pos() + 3 > end_bit) return INF_ERR_INPUT;
         br.refill();
@@ -253,10 +264,8 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
             const uint64_t byte = br.bit_pos() >> 3;
             if ((byte + len) * 8 > end_bit) return INF_ERR_INPUT;
             if (pos + len > out_len) return INF_ERR_OUTPUT;
-            flush();
             for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = file8[byte + i];
             pos += len;
-            pend_start = pos;
             br.init(byte + len);
         } else {
             int n_lit, n_dist;
@@ -281,7 +290,7 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     if (lane == 0) S.cl_lens[kClOrder[i]] = (uint8_t)v;
                 }
                 WAVE_SYNC();
-                if (const uint32_t e = build_code<CL_BITS>(S.cl_lens, 19, S.cl, S.sorted_cl, &S.cs_cl, S.cnt, false, lane)) return e;
+                if (const uint32_t e = uni(build_code<CL_BITS>(S.cl_lens, 19, S.cl, S.sorted_cl, &S.cs_cl, S.cnt, false, lane))) return e;
                 const int total = n_lit + n_dist;
                 int i = 0;
                 uint32_t prev = 0;
@@ -319,21 +328,53 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 if (uni(S.lens[256]) == 0) return INF_ERR_NOEOB;
             }
             if (btype == 2 || !fixed_ready) {
-                if (const uint32_t e = build_code<LIT_BITS>(S.lens, n_lit, S.lit, S.sorted_lit, &S.cs_lit, S.cnt, true, lane)) return e;
-                if (const uint32_t e = build_code<DIST_BITS>(S.lens + n_lit, n_dist, S.dist, S.sorted_dist, &S.cs_dist, S.cnt, true, lane)) return e;
+                if (const uint32_t e = uni(build_code<LIT_BITS>(S.lens, n_lit, S.lit, S.sorted_lit, &S.cs_lit, S.cnt, true, lane))) return e;
+                if (const uint32_t e = uni(build_code<DIST_BITS>(S.lens + n_lit, n_dist, S.dist, S.sorted_dist, &S.cs_dist, S.cnt, true, lane))) return e;
                 fixed_ready = btype == 1;
             }
             for (;;) {
-                br.refill();
-                const uint32_t e = decode_sym<LIT_BITS>(br.buf, S.lit, S.sorted_lit, &S.cs_lit);
-                if (!e) return INF_ERR_SYMBOL;
+                uint32_t e;
+                for (;;) {  // a run of literals: the loop the kernel lives in
+                    // Speculative decode: lane k looks up the code that WOULD start k bits on; the wave then walks the
+                    // chain of real code starts through those entries with v_readlane (no memory in the chain) and all
+                    // literals of the window leave in one store.  One LDS access per ~5 literals instead of one each.
+                    br.refill();
+                    const int K = br.cnt - 15;  // a code that starts at offset <= K has all its bits (and 5 to spare) in buf
+                    const uint32_t mine = S.lit[(uint32_t)(br.buf >> lane) & ((1u << LIT_BITS) - 1u)];
+                    uint64_t starts = 0;
+                    int k = 0;
+                    bool more = false;
+                    for (;;) {
+                        e = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
+                        if (e & kNotLiteral) break;
+                        starts |= 1ull << k;
+                        k += (int)(e & 15u);
+                        if (k > K) {
+                            more = true;
+                            break;
+                        }
+                    }
+                    if (starts) {
+                        const uint32_t n = (uint32_t)__popcll(starts);
+                        if (pos + n > out_len) return INF_ERR_OUTPUT;
+                        if ((starts >> lane) & 1ull) dst[pos + (uint32_t)__popcll(starts & below)] = (uint8_t)(mine >> 4);
+                        pos += n;
+                    }
+                    br.drop(k);
+                    if (!more) break;
+                }
+                br.refill();  // the window may have left as few as 15 bits: the code below and its extra bits take up to 20
+                e &= ~kNotLiteral;
+                if ((e & 15u) == 0) {
+                    e = uni(long_sym<LIT_BITS>((uint32_t)br.buf, S.sorted_lit, &S.cs_lit));
+                    if (!e) return INF_ERR_SYMBOL;
+                }
                 br.drop((int)(e & 15u));
                 const uint32_t sym = e >> 4;
-                if (sym < 256) {
+                if (sym < 256) {  // a literal with a long code
                     if (pos >= out_len) return INF_ERR_OUTPUT;
-                    pend = (uint32_t)lane == (pos & 63u) ? (int)sym : pend;
+                    if (lane == 0) dst[pos] = (uint8_t)sym;
                     ++pos;
-                    if ((pos & 63u) == 0) flush();
                     continue;
                 }
                 if (sym == 256) break;
@@ -362,7 +403,6 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 }
                 if (dist > pos) return INF_ERR_DIST;
                 if (pos + len > out_len) return INF_ERR_OUTPUT;
-                flush();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the copy reads what this wave has stored
                 const uint8_t* src = dst + (pos - dist);
                 if (dist >= len) {
@@ -371,14 +411,12 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = src[i % dist];
                 }
                 pos += len;
-                pend_start = pos;
                 if (br.bit_pos() > end_bit) return INF_ERR_INPUT;
             }
             if (br.bit_pos() > end_bit) return INF_ERR_INPUT;
         }
         if (bfinal) break;
     }
-    flush();
     if (pos != out_len) return INF_ERR_SHORT;
     return INF_OK;
 }

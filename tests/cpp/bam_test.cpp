@@ -17,11 +17,12 @@ int main(int argc, char** argv)
         std::fprintf(stderr, "usage: bam_test file.bam regionStart regionEnd [--call] [--time] [--threads N]\n");
         return 2;
     }
-    bool call = false, time_only = false, direct = false;
+    bool call = false, time_only = false, direct = false, on_device = false;
     unsigned threads = 4;
     for (int i = 4; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--call")) call = true;
         if (!std::strcmp(argv[i], "--direct")) direct = true;
+        if (!std::strcmp(argv[i], "--device")) direct = on_device = true;  // the file decoded on the GPU (BamToReadSourceDevice)
         if (!std::strcmp(argv[i], "--time")) time_only = true;
         if (!std::strcmp(argv[i], "--top-pad") && i + 1 < argc) mallopt(M_TOP_PAD, std::atoi(argv[++i]) << 20);  // experiment: arena growth step, MB
         if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)std::atoi(argv[++i]);
@@ -35,7 +36,10 @@ int main(int argc, char** argv)
             for (int rep = 0; rep < (time_only ? 2 : 1); ++rep) {
                 const auto l0 = std::chrono::steady_clock::now();
                 std::vector<std::string> chems;
-                const Data::ReadSource source = IO::BamUtils::BamToReadSource(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), threads, &tm, &chems);
+                bool used_device = false;
+                const Data::ReadSource source = on_device ? IO::BamUtils::BamToReadSourceDevice(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), threads, &tm, &chems, &used_device)
+                                                          : IO::BamUtils::BamToReadSource(argv[1], std::atoi(argv[2]), std::atoi(argv[3]), threads, &tm, &chems);
+                if (on_device && !time_only && rep == 0) std::printf("FRONT %s\n", used_device ? "device" : "host");
                 const auto c0 = std::chrono::steady_clock::now();
                 Juliet::AminoAcidCaller aac(source, error, s);
                 const auto c1 = std::chrono::steady_clock::now();

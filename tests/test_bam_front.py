@@ -310,7 +310,7 @@ def test_bam_to_counts_matches_oracle(tmp_path, ref, rich):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("staging", ["compact", "records"])
+@pytest.mark.parametrize("staging", ["compact", "records", "device"])
 @pytest.mark.parametrize("rich,clean,region", [(False, True, (31, 391)), (True, True, (0, INT_MAX)), (True, False, (100, 300))])
 def test_direct_decode_equals_array_read_path(tmp_path, monkeypatch, ref, rich, clean, region, staging):
     """BamToReadSource + AminoAcidCaller(ReadSource) -- records decoded straight into the device packer's staging
@@ -319,7 +319,9 @@ def test_direct_decode_equals_array_read_path(tmp_path, monkeypatch, ref, rich, 
     QUAL and mixed rich tags (`clean=False`: those only through the read tables, the caller refuses 'N' cigars)."""
     # staging: the decoder translates base by base into one byte each (fillCompact, the default), or writes the 8-byte
     # records; with thresholds in the environment that mask bases (the front reads them per MSA, QvThresholds.cpp:45-56)
-    monkeypatch.setenv("MSQ_PACK_WIDE_STAGING", "0" if staging == "compact" else "1")
+    # ... or the whole file is decoded on the GPU (BamToReadSourceDevice: inflate, record chain, filters, decode, pack)
+    monkeypatch.setenv("MSQ_PACK_WIDE_STAGING", "1" if staging == "records" else "0")
+    how = "--device" if staging == "device" else "--direct"
     if rich:
         monkeypatch.setenv("QUALQV", "30")
         monkeypatch.setenv("DELQV", "40")
@@ -330,8 +332,10 @@ def test_direct_decode_equals_array_read_path(tmp_path, monkeypatch, ref, rich, 
     want = expected_reads(recs, *region)
     if clean:
         rc_a, reads_a, rest_a = run_bam_test(path, *region, "--call")
-        rc_d, _, rest_d = run_bam_test(path, *region, "--call", "--direct", "--threads", "7")
+        rc_d, _, rest_d = run_bam_test(path, *region, "--call", how, "--threads", "7")
         assert rc_a == 0 and rc_d == 0
+        if staging == "device":
+            assert "FRONT device" in rest_d
         src = [l.split(" ") for l in rest_d if l.startswith("SRC ")]
         assert [(int(t[1]), int(t[2]), int(t[3]), t[5]) for t in src] == [(w[0], w[1], len(w[2]), w[5]) for w in want]
         body = lambda rest: [l for l in rest if l.split(" ")[0] in ("CASE", "BEGIN", "NUC", "CODON", "NTESTS", "VAR", "MSA", "PERF")]
@@ -345,11 +349,51 @@ def test_direct_decode_equals_array_read_path(tmp_path, monkeypatch, ref, rich, 
         chems = [l.split(" ")[1] for l in rest_d if l.startswith("CHEMS ")]
         assert chems == [CHEM["abcd1234"]]
     else:
-        rc_d, _, rest_d = run_bam_test(path, *region, "--call", "--direct")
+        rc_d, _, rest_d = run_bam_test(path, *region, "--call", how)
         src = [l.split(" ") for l in rest_d if l.startswith("SRC ")]
         if rc_d == 0:  # no 'N' / 'M' cigar survived the region
+            if staging == "device":
+                assert "FRONT device" in rest_d
             assert [(int(t[1]), int(t[2]), int(t[3]), t[5]) for t in src] == [(w[0], w[1], len(w[2]), w[5]) for w in want]
         else:  # the caller's own refusal, as through the ArrayRead path (src/MSA.cpp:182)
             assert any(l.startswith("ERR Unexpected cigar") for l in rest_d)
             rc_a, _, rest_a = run_bam_test(path, *region, "--call")
             assert rc_a == 1 and [l for l in rest_a if l.startswith("ERR")] == [l for l in rest_d if l.startswith("ERR")]
+
+
+@pytest.mark.gpu
+def test_device_front_reports_errors_like_the_host_front(tmp_path, ref):
+    """Files the device front declines go through the host front: the same exception text, in file order."""
+    rng = np.random.default_rng(9)
+    good = str(tmp_path / "g.bam")
+    write_bam(good, make_records(rng, ref, 40, clean=True), len(ref), block=3000)
+    data = bytearray(open(good, "rb").read())
+    bad = str(tmp_path / "bad.bam")
+    blobs = [bytes(data[:len(data) // 2]), b"this is not a BGZF file at all........"]
+    d = bytearray(data)
+    d[40] ^= 0x55          # inside the first block's DEFLATE payload
+    blobs.append(bytes(d))
+    d = bytearray(data)
+    d[len(d) // 2] ^= 0xFF  # somewhere in a later block
+    blobs.append(bytes(d))
+    text = b"@HD\tVN:1.5\n"
+    raw = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", 1) + struct.pack("<I", 0x7FFFFFF0) + b"ref\0"
+    blobs.append(bgzf_block(raw) + bgzf_block(b""))
+    blobs.append(bgzf_block(b"BAX\1" + raw[4:]) + bgzf_block(b""))
+    recs = make_records(rng, ref, 25, clean=True)
+    head = b"BAM\1" + struct.pack("<I", len(text)) + text + struct.pack("<I", 1) + struct.pack("<I", 4) + b"ref\0" + struct.pack("<I", len(ref))
+    body = b"".join(encode_record(r) for r in recs)
+    blobs.append(bgzf_block(head + body[:-9]) + bgzf_block(b""))                      # a record cut short
+    blobs.append(bgzf_block(head + body[:300]) + bgzf_block(body[300:] + b"\0\0\0\0" + b"x" * 40) + bgzf_block(b""))  # block_size 0
+    for k, blob in enumerate(blobs):
+        open(bad, "wb").write(blob)
+        rc_h, _, rest_h = run_bam_test(bad, 0, INT_MAX, "--call", "--direct")
+        rc_d, _, rest_d = run_bam_test(bad, 0, INT_MAX, "--call", "--device")
+        assert rc_h == 1 and rc_d == 1, k
+        assert [l for l in rest_h if l.startswith("ERR")] == [l for l in rest_d if l.startswith("ERR")] != [], k
+    rc_d, _, rest_d = run_bam_test(good, 0, INT_MAX, "--call", "--device")
+    assert rc_d == 0 and "FRONT device" in rest_d
+    # an empty file of records: juliet's "Empty input." case, no reads from either front
+    write_bam(bad, [], len(ref))
+    rc_d, _, rest_d = run_bam_test(bad, 0, INT_MAX, "--device")
+    assert rc_d == 0 and "FRONT device" in rest_d and not [l for l in rest_d if l.startswith("SRC ")]

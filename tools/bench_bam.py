@@ -89,7 +89,11 @@ def main():
     ap.add_argument("--call", action="store_true", help="also time AminoAcidCaller on the decoded reads (needs the GPU)")
     ap.add_argument("--extra", default="", help="extra arguments for bam_test (experiments)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--write-only", default="", help="write the synthetic BAM to this path and stop (for profiling runs of bam_test)")
     a = ap.parse_args()
+    if a.write_only:
+        write(a.write_only, a.reads, a.columns, a.rich)
+        return 0
     assert os.path.exists(BIN), "tests/cpp/bam_test not built: run __graft_entry__.build()"
     lines = []
     with tempfile.TemporaryDirectory() as d:
