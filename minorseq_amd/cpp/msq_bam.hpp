@@ -533,17 +533,20 @@ struct BamUtils
             }
             if (!ok) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);  // "not a BAM file" / "truncated BAM header"
         }
+        const auto t3 = Clock::now();
         {
             const int rc = msq_bam_index_device(ctx, dev->bam, first, nRef, regionStart0, regionEnd0, &nRecords, &nKept);
             if (rc == MSQ_ERR_DATA) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);
             Msq::Check(rc);
         }
+        const auto t4 = Clock::now();
         std::vector<msq_bam_record> kept(nKept);
         Msq::Check(msq_bam_records(ctx, dev->bam, kept.data()));
         uint64_t nameBytes = 0;
         for (const auto& k : kept) nameBytes += k.l_read_name;
         std::vector<char> nameBuf(nameBytes + 1);
         Msq::Check(msq_bam_names(ctx, dev->bam, nameBuf.data(), nameBytes));
+        const auto t5 = Clock::now();
         Data::ReadSource source;
         source.names.resize(nKept);
         source.referenceStart.resize(nKept);
@@ -607,6 +610,9 @@ struct BamUtils
             return DecodeBasesCompact(&L.data[k.off], k.block_size, k.ref_start, k.ref_end, lazy->regionStart, lazy->regionEnd, lazy->path, thr, dst, presence);
         };
         if (usedDevice) *usedDevice = true;
+        if (std::getenv("MSQ_BAM_TRACE"))
+            std::fprintf(stderr, "BamToReadSourceDevice: map + scan %.2f ms, inflate %.2f, header %.2f, index %.2f, records + names %.2f, source %.2f\n",
+                         1e3 * secs(t0, t1), 1e3 * secs(t1, t2), 1e3 * secs(t2, t3), 1e3 * secs(t3, t4), 1e3 * secs(t4, t5), 1e3 * secs(t5, Clock::now()));
         if (timings) {
             timings->read = secs(t0, t1);
             timings->inflate = secs(t1, t2);

@@ -19,6 +19,7 @@
 #include "msq_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <vector>
 
@@ -396,6 +397,10 @@ extern "C" int msq_bam_index_device(msq_ctx* ctx, msq_bam_dev* bam, uint64_t fir
     bam->h_kept.clear();
     bam->region_start0 = region_start0;
     bam->region_end0 = region_end0;
+    const bool trace = getenv("MSQ_BAM_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&t0]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    double t_chain = 0, t_records = 0;
     const uint64_t span = bam->data_bytes - first_record_off;
     const uint64_t seg = std::max<uint64_t>(64, ctx->bam_segment_bytes);
     const uint64_t n_seg = (span + seg - 1) / seg;
@@ -429,6 +434,7 @@ extern "C" int msq_bam_index_device(msq_ctx* ctx, msq_bam_dev* bam, uint64_t fir
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) return hip_fail("chain kernel", e);
         }
+        t_chain = ms_since();
         // the induction: the chain enters segment k at `cur`; the segment's own guess must be that very offset
         uint64_t cur = first_record_off;
         for (uint64_t k = 0; k < n_seg; ++k) {
@@ -468,6 +474,8 @@ extern "C" int msq_bam_index_device(msq_ctx* ctx, msq_bam_dev* bam, uint64_t fir
             if (e == hipSuccess) e = hipMemcpyAsync(all.data(), bam->d_rec, total * sizeof(msq_bam_record), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) return hip_fail("record kernel", e);
+            t_records = ms_since();
+            bam->h_kept.reserve(total);
             for (uint64_t r = 0; r < total; ++r) {
                 const msq_bam_record& k = all[r];
                 if (k.status == MSQ_BAM_REC_SKIP) continue;
@@ -480,7 +488,10 @@ extern "C" int msq_bam_index_device(msq_ctx* ctx, msq_bam_dev* bam, uint64_t fir
                 }
                 bam->h_kept.push_back(k);
             }
-            if (!bam->h_kept.empty()) {
+            if (bam->h_kept.size() == total) {  // every record kept: the table in HBM is the kept table
+                bam->d_kept = bam->d_rec;
+                bam->d_rec = nullptr;
+            } else if (!bam->h_kept.empty()) {
                 e = hipMalloc((void**)&bam->d_kept, bam->h_kept.size() * sizeof(msq_bam_record));
                 if (e == hipSuccess) e = hipMemcpyAsync(bam->d_kept, bam->h_kept.data(), bam->h_kept.size() * sizeof(msq_bam_record), hipMemcpyHostToDevice, ctx->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -494,6 +505,9 @@ extern "C" int msq_bam_index_device(msq_ctx* ctx, msq_bam_dev* bam, uint64_t fir
     }
     bam->n_records = total;
     bam->n_kept = bam->h_kept.size();
+    if (trace)
+        std::fprintf(stderr, "msq_bam_index_device: %llu segments, %llu records, %llu kept: chain %.2f ms, records back at %.2f ms, done at %.2f ms\n",
+                     (unsigned long long)n_seg, (unsigned long long)total, (unsigned long long)bam->n_kept, t_chain, t_records, ms_since());
     if (n_records) *n_records = total;
     if (n_kept) *n_kept = bam->n_kept;
     return MSQ_OK;

@@ -24,6 +24,7 @@
 #include "msq_internal.h"
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <vector>
 
@@ -341,19 +342,31 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     br.refill();
                     const int K = br.cnt - 15;  // a code that starts at offset <= K has all its bits (and 5 to spare) in buf
                     const uint32_t mine = S.lit[(uint32_t)(br.buf >> lane) & ((1u << LIT_BITS) - 1u)];
-                    uint64_t starts = 0;
-                    int k = 0;
-                    bool more = false;
-                    for (;;) {
-                        e = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
-                        if (e & kNotLiteral) break;
-                        starts |= 1ull << k;
-                        k += (int)(e & 15u);
-                        if (k > K) {
-                            more = true;
-                            break;
-                        }
-                    }
+                    // the chain walk, eight scalar instructions per literal (hand-written: the compiler's version of this
+                    // loop took thirteen, and the kernel is bound by instruction issue): starts = the offsets where a
+                    // literal's code starts, k = the offset behind the last one, e = the entry that ended the walk,
+                    // more = the walk ended at the window's end, not at a non-literal
+                    uint64_t starts;
+                    int k, more;
+                    uint32_t tmp;
+                    asm volatile(
+                        "s_mov_b64 %[st], 0\n\t"
+                        "s_mov_b32 %[k], 0\n\t"
+                        "s_mov_b32 %[more], 0\n"
+                        "1:\n\t"
+                        "v_readlane_b32 %[e], %[mine], %[k]\n\t"
+                        "s_bitcmp1_b32 %[e], 15\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "s_bitset1_b64 %[st], %[k]\n\t"
+                        "s_and_b32 %[t], %[e], 15\n\t"
+                        "s_add_i32 %[k], %[k], %[t]\n\t"
+                        "s_cmp_le_i32 %[k], %[K]\n\t"
+                        "s_cbranch_scc1 1b\n\t"
+                        "s_mov_b32 %[more], 1\n"
+                        "2:"
+                        : [st] "=&s"(starts), [k] "=&s"(k), [e] "=&s"(e), [more] "=&s"(more), [t] "=&s"(tmp)
+                        : [mine] "v"(mine), [K] "s"(K)
+                        : "scc");
                     if (starts) {
                         const uint32_t n = (uint32_t)__popcll(starts);
                         if (pos + n > out_len) return INF_ERR_OUTPUT;
@@ -461,46 +474,104 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
         total += k.out_len;
     }
     MSQ_HIP(hipSetDevice(ctx->device));
+    const bool trace = getenv("MSQ_BAM_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&t0]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     msq_bam_dev* b = new (std::nothrow) msq_bam_dev;
     if (!b) return msq_fail(MSQ_ERR_NOMEM, "msq_bgzf_inflate_device: out of memory");
-    void *d_file = nullptr, *d_members = nullptr, *d_status = nullptr;
+    // the file image, the member table and the status words live in the context's scratch (no allocation per call once it
+    // has grown); the inflated stream is the caller's to keep
+    const uint64_t file_padded = ((file_bytes + 3) & ~3ull) + 1024;  // the bit reader looks two chunks ahead
+    const uint64_t table_bytes = (std::max<uint64_t>(n_members, 1) * sizeof(msq_bgzf_member) + 255) & ~255ull;
+    const uint64_t status_bytes = (std::max<uint64_t>(n_members, 1) * 4 + 255) & ~255ull;
+    void* scratch = nullptr;
+    if (int rc = msq_scratch(ctx, file_padded + 256 + table_bytes + status_bytes, &scratch)) {
+        delete b;
+        return rc;
+    }
+    char* const d_file = (char*)scratch;
+    char* const d_members = d_file + ((file_padded + 255) & ~255ull);
+    char* const d_status = d_members + table_bytes;
     auto fail = [&](int code, const char* what, hipError_t e) {
         (void)hipStreamSynchronize(ctx->stream);
-        for (void* p : {d_file, d_members, d_status})
-            if (p) (void)hipFree(p);
+        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
         free_bam_dev(b);
         return msq_fail(code, "msq_bgzf_inflate_device: %s: %s", what, hipGetErrorString(e));
     };
-    const uint64_t file_padded = ((file_bytes + 3) & ~3ull) + 1024;  // the bit reader looks two chunks ahead
-    const uint64_t data_padded = total + MSQ_BAM_DATA_PAD;
-    hipError_t e = hipMalloc(&d_file, file_padded);
-    if (e == hipSuccess) e = hipMalloc(&d_members, std::max<uint64_t>(n_members, 1) * sizeof(msq_bgzf_member));
-    if (e == hipSuccess) e = hipMalloc(&d_status, std::max<uint64_t>(n_members, 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->d_data, data_padded);
+    hipError_t e = hipMalloc((void**)&b->d_data, total + MSQ_BAM_DATA_PAD);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "hipMalloc", e);
     b->data_bytes = total;
-    e = hipMemsetAsync((char*)d_file + (file_bytes & ~3ull), 0, file_padded - (file_bytes & ~3ull), ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(b->d_data + total, 0, MSQ_BAM_DATA_PAD, ctx->stream);
-    if (e == hipSuccess && file_bytes) e = hipMemcpyAsync(d_file, file, file_bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && n_members) e = hipMemcpyAsync(d_members, members, n_members * sizeof(msq_bgzf_member), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_status, 0xFF, std::max<uint64_t>(n_members, 1) * 4, ctx->stream);
-    if (e != hipSuccess) return fail(MSQ_ERR_HIP, "upload", e);
+    const double t_alloc = ms_since();
+    if (!ctx->copy_stream) {
+        e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail(MSQ_ERR_HIP, "hipStreamCreate", e);
+    }
     std::vector<uint32_t> status;
     try {
         status.resize(n_members);
     } catch (const std::bad_alloc&) {
         return fail(MSQ_ERR_NOMEM, "status", hipErrorOutOfMemory);
     }
-    if (n_members) {
-        hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((n_members + 3) / 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_file,
-                           file_padded / 4, (const msq_bgzf_member*)d_members, (uint32_t)n_members, b->d_data, (uint32_t*)d_status);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(status.data(), d_status, n_members * 4, hipMemcpyDeviceToHost, ctx->stream);
+    e = hipMemsetAsync(d_file + (file_bytes & ~3ull), 0, file_padded - (file_bytes & ~3ull), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_data + total, 0, MSQ_BAM_DATA_PAD, ctx->stream);
+    if (e == hipSuccess && n_members) e = hipMemcpyAsync(d_members, members, n_members * sizeof(msq_bgzf_member), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_status, 0xFF, status_bytes, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the scratch's previous user is done, the padding is written
+    if (e != hipSuccess) return fail(MSQ_ERR_HIP, "upload", e);
+    // The file crosses PCIe in pieces on a stream of its own while the members of the pieces before are inflated: the
+    // copy of a pageable mapping keeps this thread busy, the kernels run beside it.  Two pieces only: a kernel takes ~6 ms
+    // however few members it has (one member is one wave, ~14 000 dependent windows of ~1100 cycles), 2.3 us per member
+    // once the chip's issue slots are full (10^5 reads: 16 ms), and the kernels of several streams did not overlap
+    // (measured: 18 pieces of 16 MB on four streams 46 ms after the copies, 4 pieces on one stream 26 ms).
+    // (A wave may look up to two chunks past its member into bytes that have not arrived: bits no valid stream consumes.)
+    std::vector<hipEvent_t> arrived;
+    auto drop_events = [&]() {
+        for (hipEvent_t ev : arrived) (void)hipEventDestroy(ev);
+        arrived.clear();
+    };
+    bool ordered = true;  // members in file order (a BGZF file's are): pieces are member ranges
+    for (uint64_t m = 1; m < n_members; ++m) ordered = ordered && members[m].in_off >= members[m - 1].in_off;
+    const uint64_t n_pieces = (ordered && file_bytes >= ((uint64_t)32 << 20)) ? std::max<uint64_t>(1, ctx->bam_pieces) : 1;
+    uint64_t copied = 0;  // file bytes on their way
+    for (uint64_t m0 = 0, piece = 0; e == hipSuccess && m0 < n_members; ++piece) {
+        uint64_t m1 = m0 + 1, upto = file_bytes;
+        if (piece + 1 < n_pieces) {  // up to the member that crosses this piece's share of the file
+            const uint64_t share = file_bytes / n_pieces * (piece + 1);
+            while (m1 < n_members && members[m1 - 1].in_off + members[m1 - 1].in_len < share) ++m1;
+            upto = members[m1 - 1].in_off + members[m1 - 1].in_len;
+        } else {
+            m1 = n_members;
+        }
+        if (upto > copied) {
+            e = hipMemcpyAsync(d_file + copied, file + copied, upto - copied, hipMemcpyHostToDevice, ctx->copy_stream);
+            copied = upto;
+            hipEvent_t ev = nullptr;
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) {
+                arrived.push_back(ev);
+                e = hipEventRecord(ev, ctx->copy_stream);
+            }
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((m1 - m0 + 3) / 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_file, file_padded / 4,
+                               (const msq_bgzf_member*)d_members + m0, (uint32_t)(m1 - m0), b->d_data, (uint32_t*)d_status + m0);
+            e = hipGetLastError();
+        }
+        m0 = m1;
     }
+    const double t_issued = ms_since();
+    if (e == hipSuccess && n_members) e = hipMemcpyAsync(status.data(), d_status, n_members * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return fail(MSQ_ERR_HIP, "inflate kernel", e);
-    for (void* p : {d_file, d_members, d_status}) (void)hipFree(p);
-    d_file = d_members = d_status = nullptr;
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        drop_events();
+        return fail(MSQ_ERR_HIP, "inflate kernel", e);
+    }
+    drop_events();
+    if (trace)
+        std::fprintf(stderr, "msq_bgzf_inflate_device: %llu members, %.1f MB -> %.1f MB: alloc %.2f ms, copies + launches issued at %.2f ms, done at %.2f ms\n",
+                     (unsigned long long)n_members, file_bytes / 1e6, total / 1e6, t_alloc, t_issued, ms_since());
     for (uint64_t m = 0; m < n_members; ++m)
         if (status[m] != INF_OK) {
             free_bam_dev(b);

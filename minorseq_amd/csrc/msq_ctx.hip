@@ -1,6 +1,7 @@
 // msq_ctx.hip -- context, error text, device-memory helpers, log-factorial table.
 #include "msq_internal.h"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -60,6 +61,7 @@ extern "C" int msq_ctx_create(int device, msq_ctx** out)
     }
     c->no_merge = std::getenv("MSQ_NO_MERGE") != nullptr;
     c->no_haps = std::getenv("MSQ_NO_HAPS") != nullptr;
+    if (const char* v = std::getenv("MSQ_BAM_PIECES")) c->bam_pieces = (uint64_t)std::max(1ll, strtoll(v, nullptr, 10));
     if (const char* v = std::getenv("MSQ_CARRIER_MIN_BATCHES")) c->carrier_min_batches = (int64_t)strtoll(v, nullptr, 10);
     *out = c;
     return MSQ_OK;
@@ -72,6 +74,7 @@ extern "C" int msq_debug_tune(msq_ctx* ctx, int key, long long value)
     case MSQ_TUNE_NO_MERGE: ctx->no_merge = value != 0; return MSQ_OK;
     case MSQ_TUNE_CARRIER_MIN_BATCHES: ctx->carrier_min_batches = (int64_t)value; return MSQ_OK;
     case MSQ_TUNE_NO_HAPS: ctx->no_haps = value != 0; return MSQ_OK;
+    case MSQ_TUNE_BAM_PIECES: ctx->bam_pieces = value < 1 ? 1 : (uint64_t)value; return MSQ_OK;
     case MSQ_TUNE_BAM_SEGMENT: ctx->bam_segment_bytes = value < 64 ? 64 : (uint64_t)value; return MSQ_OK;
     default: return msq_fail(MSQ_ERR_ARG, "msq_debug_tune: unknown key %d", key);
     }
@@ -118,6 +121,7 @@ extern "C" int msq_ctx_destroy(msq_ctx* ctx)
         if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
         if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);
     }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     timing_release(ctx);
     delete ctx;
     return MSQ_OK;

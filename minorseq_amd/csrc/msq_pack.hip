@@ -663,6 +663,48 @@ static int pack_reads_device_impl(msq_ctx* ctx, uint64_t n_reads, const int32_t*
     return MSQ_OK;
 }
 
+// pack_groups_kernel's compact mode for bytes that are all in HBM already: a wave per READ walks its bases 64 at a time
+// (two groups), so no group has to look for its read (the binary search over the read tables was most of that kernel's
+// 3.8 ms per 10^5 reads here).  Same slots, same planes.
+__global__ __launch_bounds__(256) void pack_compact_reads_kernel(const uint8_t* __restrict__ compact, const uint64_t* __restrict__ base_off,
+                                                                 const uint64_t* __restrict__ group_off, uint64_t n_reads, uint4* __restrict__ bop,
+                                                                 uint32_t* __restrict__ flags, int plain)
+{
+    __shared__ uint8_t nib[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, k = lane & 31;
+    const uint64_t r = (uint64_t)blockIdx.x * 4 + (uint64_t)wave;
+    if (r >= n_reads) return;
+    const uint64_t b0 = base_off[r], len = base_off[r + 1] - b0, g0 = group_off[r], ng = group_off[r + 1] - g0;
+    const uint32_t below = (1u << k) - 1u;
+    uint32_t seen = 0;
+    for (uint64_t i0 = 0; i0 < len; i0 += 64) {
+        const uint64_t i = i0 + (uint64_t)lane;
+        const bool has = i < len;
+        const uint8_t c8 = has ? compact[b0 + i] : (uint8_t)0;
+        const unsigned code = has ? (c8 & 3u) : 0u, op = has ? ((c8 >> 2) & 3u) : 3u;
+        seen |= c8 & 0x30u;
+        const bool cons = has && op < 2, ncons = has && op >= 2;
+        const uint32_t hc = (uint32_t)(__ballot(cons) >> (32 * h)), hn = (uint32_t)(__ballot(ncons) >> (32 * h));
+        const int slot = plain ? k : cons ? __popc(hc & below) : 31 - __popc(hn & below);
+        nib[wave][lane] = plain ? 15 : 12;  // padding: op 3
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (has) nib[wave][h * 32 + slot] = (uint8_t)(code | (op << 2));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned v = nib[wave][lane];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t p0 = __ballot(v & 1u), p1 = __ballot(v & 2u), p2 = __ballot(v & 4u), p3 = __ballot(v & 8u);
+        const uint64_t gi = i0 / 32 + (uint64_t)h;
+        if (k == 0 && gi < ng)
+            bop[g0 + gi] = make_uint4((uint32_t)(p0 >> (32 * h)), (uint32_t)(p1 >> (32 * h)), (uint32_t)(p2 >> (32 * h)), (uint32_t)(p3 >> (32 * h)));
+    }
+    const bool exotic = __ballot(seen & 16u) != 0, ins_exotic = __ballot(seen & 32u) != 0;
+    if (lane == 0 && exotic) atomicOr(flags, MSQ_READS_HAS_EXOTIC);
+    if (lane == 0 && ins_exotic) atomicOr(flags, MSQ_READS_INS_EXOTIC);
+}
+
 // The device packer over translated bytes that are already in HBM (the BAM front on the device, msq_bam_pack_device):
 // the tail of pack_reads_device_impl without staging -- read tables up, one pack_groups_kernel over all groups, flags,
 // column index.  Same packed bytes as msq_pack_reads_device_fill_compact on the same bytes.
@@ -685,7 +727,6 @@ int msq_pack_compact_resident(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref
     const uint64_t n_groups = group_off[n_reads];
     void* scratch = nullptr;
     if (int rc = msq_scratch(ctx, 256, &scratch)) return rc;
-    unsigned long long* d_errword = (unsigned long long*)scratch;
     uint32_t* d_flags = (uint32_t*)((char*)scratch + 8);
     MSQ_HIP(hipMemsetAsync(scratch, 0xFF, 8, ctx->stream));
     MSQ_HIP(hipMemsetAsync(d_flags, 0, 8, ctx->stream));
@@ -703,12 +744,11 @@ int msq_pack_compact_resident(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref
         if (e == hipSuccess && bytes[k] && src[k]) e = hipMemcpyAsync(d->ptrs[k], src[k], bytes[k], hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "read tables", e);
     }
-    if (n_groups) {
-        const uint64_t blocks = (n_groups + 7) / 8;  // 4 waves x 2 groups
-        if (blocks > 0x7fffffffull) return fail(MSQ_ERR_ARG, "too many groups for one launch", hipErrorInvalidValue);
-        hipLaunchKernelGGL(pack_groups_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const uint64_t*>(d_compact), (uint64_t)0,
-                           d_base_off, (const uint64_t*)d->ptrs[2], (uint64_t)0, n_reads, (uint64_t)0, n_groups, (uint4*)d->ptrs[3], (uint8_t*)nullptr,
-                           (uint8_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)nullptr, d_errword, d_flags, plain, 1, thr, 1);
+    if (n_reads) {
+        const uint64_t blocks = (n_reads + 3) / 4;  // a wave per read
+        if (blocks > 0x7fffffffull) return fail(MSQ_ERR_ARG, "too many reads for one launch", hipErrorInvalidValue);
+        hipLaunchKernelGGL(pack_compact_reads_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_compact, d_base_off, (const uint64_t*)d->ptrs[2],
+                           n_reads, (uint4*)d->ptrs[3], d_flags, plain);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(MSQ_ERR_HIP, "pack kernel", e);
     }
