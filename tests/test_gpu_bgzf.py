@@ -126,6 +126,24 @@ def test_many_members_and_odd_payload_offsets(ctx):
     assert len({m[0] & 3 for m in members}) == 4
 
 
+def test_bam_shaped_members(ctx, tmp_path):
+    """Members the way a BAM writer makes them: 65280-byte payloads of records (packed bases, quality bytes, names, tags)
+    at level 1 -- long literal runs that end in a length code with extra bits right at the edge of the speculative window
+    (the case a first version of the literal decode lost: it left too few bits behind the window)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_bam
+    for rich, reads in ((False, 1500), (True, 500)):
+        path = str(tmp_path / "b.bam")
+        bench_bam.write(path, reads, 2843, rich)
+        blob = open(path, "rb").read()
+        members = scan(blob)
+        assert len(members) > 90
+        want = b"".join(zlib.decompress(blob[m[0]:m[0] + m[2]], -15) for m in members)
+        assert inflate_device(ctx, blob, members) == want
+
+
 def zlib_outcome(payload, isize):
     """What the host front's inflate makes of a member: its bytes, or None when it refuses (not Z_STREAM_END within isize)."""
     d = zlib.decompressobj(-15)

@@ -113,7 +113,8 @@ def main():
                 if best is None or total < best[0]:
                     best = (total, kv)
             total, kv = best
-            line = {"what": "BAM -> ArrayReads (host)", "threads": t, "reads": int(kv["kept"]), "columns": a.columns, "rich_qvs": a.rich,
+            front = "device" if "--device" in a.extra else "host, direct decode" if "--direct" in a.extra else "host, ArrayReads"
+            line = {"what": "BAM file -> reads (%s front)" % front, "threads": t, "reads": int(kv["kept"]), "columns": a.columns, "rich_qvs": a.rich,
                     "reads_per_s": kv["kept"] / total, "bam_MB_per_s": kv["bam_bytes"] / total / 1e6, "seconds": total,
                     "read_s": kv["read_s"], "inflate_s": kv["inflate_s"], "index_s": kv["index_s"], "parse_s": kv["parse_s"],
                     "file_MB": kv["file_bytes"] / 1e6, "bam_MB": kv["bam_bytes"] / 1e6}
@@ -121,6 +122,7 @@ def main():
                 line["caller_s"] = kv["call_s"]
                 line["caller_first_s"] = kv["call_first_s"]
                 line["end_to_end_reads_per_s"] = kv["kept"] / (total + kv["call_s"])
+                line["inflate_share"] = kv["inflate_s"] / (total + kv["call_s"])
                 for k in ("phase_s", "json_s", "haplotypes", "json_bytes"):
                     if k in kv:
                         line[k] = kv[k]
