@@ -24,6 +24,7 @@ MSQ_READS_ALIGNED = 32
 MSQ_PACK_PLAIN = 1
 MSQ_COMM_ID_BYTES = 128
 MSQ_TUNE_NO_MERGE, MSQ_TUNE_CARRIER_MIN_BATCHES, MSQ_TUNE_NO_HAPS, MSQ_TUNE_BAM_SEGMENT, MSQ_TUNE_BAM_PIECES = 1, 2, 3, 4, 5
+MSQ_TUNE_BAM_PIECE_MIN_BYTES = 6
 MSQ_BAM_REC_SKIP, MSQ_BAM_REC_KEEP, MSQ_BAM_REC_MALFORMED, MSQ_BAM_REC_CIGAR, MSQ_BAM_REC_MSA = 0, 1, 2, 3, 4
 
 

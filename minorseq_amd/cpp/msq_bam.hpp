@@ -163,6 +163,21 @@ struct Deflater {
     }
 };
 
+// one member's payload through zlib: true when it inflates to exactly out_len bytes
+inline bool InflateMember(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len)
+{
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef*>(in);
+    zs.avail_in = (uInt)in_len;
+    zs.next_out = out;
+    zs.avail_out = (uInt)out_len;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.avail_out == 0;
+}
+
 // BGZF (SAMv1 4.1): gzip members with FEXTRA holding the subfield 'B','C',2,BSIZE.  Where the members are and what
 // they inflate to; *total = the inflated stream's length.
 inline std::vector<BgzfBlock> ScanBgzf(const MappedFile& file, size_t* total)
@@ -475,6 +490,8 @@ struct BamUtils
         uint64_t nRecords = 0, nKept = 0;
         std::vector<std::pair<std::string, std::string>> readGroups;
         Clock::time_point t1, t2;
+        uint64_t first = 0;
+        int32_t nRef = 0;
         {
             const MappedFile file(filePath);
             fileBytes = file.size();
@@ -482,56 +499,52 @@ struct BamUtils
             std::vector<msq_bgzf_member> members(blocks.size());
             for (size_t b = 0; b < blocks.size(); ++b)
                 members[b] = msq_bgzf_member{(uint64_t)blocks[b].in_off, (uint64_t)blocks[b].out_off, (uint32_t)blocks[b].in_len, (uint32_t)blocks[b].out_len};
+            // The BAM header (text with the read groups, reference names; the first record sits behind it) is read from the
+            // first members on the host -- a few KB of zlib work instead of a round trip after the device's inflate.
+            {
+                std::vector<uint8_t> head;
+                size_t nextBlock = 0;
+                auto need = [&](uint64_t n) {  // the first n bytes of the stream, or the host front's refusal
+                    if (n > bamBytes) return false;
+                    while (head.size() < n) {
+                        if (nextBlock >= blocks.size()) return false;
+                        const BgzfBlock& k = blocks[nextBlock++];
+                        const size_t at = head.size();
+                        head.resize(at + k.out_len);
+                        if (k.out_len && !InflateMember(&file[k.in_off], k.in_len, head.data() + at, k.out_len)) return false;
+                    }
+                    return true;
+                };
+                bool ok = need(12) && std::memcmp(head.data(), "BAM\1", 4) == 0;
+                uint64_t off = 4;
+                size_t lText = 0;
+                if (ok) {
+                    lText = U32(&head[off]);
+                    ok = need(off + 4 + lText + 4);
+                }
+                if (ok) {
+                    readGroups = ReadGroupChemistries(std::string(reinterpret_cast<const char*>(&head[off + 4]), lText));
+                    off += 4 + lText;
+                    const size_t n = U32(&head[off]);
+                    off += 4;
+                    for (size_t r = 0; ok && r < n; ++r) {
+                        ok = need(off + 4);
+                        if (!ok) break;
+                        const size_t lName = U32(&head[off]);
+                        ok = lName <= bamBytes && need(off + 4 + lName + 4);
+                        off += 4 + lName + 4;
+                    }
+                    ok = ok && n <= 0x7fffffffu;
+                    nRef = (int32_t)n;
+                    first = off;
+                }
+                if (!ok) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);  // "not a BAM file" / "truncated BAM header" / a block that does not inflate
+            }
             t1 = Clock::now();
             const int rc = msq_bgzf_inflate_device(ctx, file.data(), file.size(), members.data(), members.size(), &dev->bam);
             if (rc == MSQ_ERR_DATA) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);
             Msq::Check(rc);
             t2 = Clock::now();
-        }
-        // the BAM header comes back (text with the read groups, reference names): the first record sits behind it
-        uint64_t first = 0;
-        int32_t nRef = 0;
-        {
-            std::vector<uint8_t> head(std::min<uint64_t>(bamBytes, 1 << 16));
-            auto need = [&](uint64_t n) {  // the first n bytes of the stream, or the host front's refusal
-                if (n > bamBytes) return false;
-                if (n > head.size()) head.resize(std::min<uint64_t>(bamBytes, std::max<uint64_t>(n, head.size() * 2)));
-                return true;
-            };
-            uint64_t have = 0;
-            auto fetch = [&]() {
-                if (have < head.size()) {
-                    Msq::Check(msq_bam_dev_read(ctx, dev->bam, have, head.size() - have, head.data() + have));
-                    have = head.size();
-                }
-            };
-            fetch();
-            bool ok = need(12) && std::memcmp(head.data(), "BAM\1", 4) == 0;
-            uint64_t off = 4;
-            size_t lText = 0;
-            if (ok) {
-                lText = U32(&head[off]);
-                ok = need(off + 4 + lText + 4);
-            }
-            if (ok) {
-                fetch();
-                readGroups = ReadGroupChemistries(std::string(reinterpret_cast<const char*>(&head[off + 4]), lText));
-                off += 4 + lText;
-                const size_t n = U32(&head[off]);
-                off += 4;
-                for (size_t r = 0; ok && r < n; ++r) {
-                    ok = need(off + 4);
-                    if (!ok) break;
-                    fetch();
-                    const size_t lName = U32(&head[off]);
-                    ok = lName <= bamBytes && need(off + 4 + lName + 4);
-                    off += 4 + lName + 4;
-                }
-                ok = ok && n <= 0x7fffffffu;
-                nRef = (int32_t)n;
-                first = off;
-            }
-            if (!ok) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);  // "not a BAM file" / "truncated BAM header"
         }
         const auto t3 = Clock::now();
         {
@@ -552,29 +565,42 @@ struct BamUtils
         source.referenceStart.resize(nKept);
         source.referenceEnd.resize(nKept);
         source.numBases.resize(nKept);
-        uint64_t at = 0;
-        std::vector<std::string> chems;
+        std::vector<uint64_t> nameAt(nKept + 1, 0);
         for (size_t r = 0; r < nKept; ++r) {
-            const msq_bam_record& k = kept[r];
-            if (k.rg_len == 254) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);  // a read group id beyond the table's 16 chars
-            source.names[r] = nameBuf.data() + at;  // up to the name's NUL
-            at += k.l_read_name;
-            source.referenceStart[r] = std::max(k.ref_start, (int32_t)regionStart0);
-            source.referenceEnd[r] = std::min(k.ref_end, (int32_t)regionEnd0);
-            source.numBases[r] = k.n_bases;
-            if (chemistries) {
-                std::string chem;
-                if (k.rg_len != 255) {
-                    const std::string id(k.rg, k.rg_len);
-                    for (const auto& g : readGroups)
-                        if (g.first == id) chem = g.second;
+            if (kept[r].rg_len == 254) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);  // a read group id beyond the table's 16 chars
+            nameAt[r + 1] = nameAt[r] + kept[r].l_read_name;
+        }
+        const unsigned workers = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, nKept / 4096 + 1));
+        std::vector<std::vector<std::string>> chemsOf(workers);  // distinct strings per worker, in order of appearance
+        auto tables = [&](unsigned w) {
+            for (size_t r = nKept * w / workers; r < nKept * (w + 1) / workers; ++r) {
+                const msq_bam_record& k = kept[r];
+                source.names[r] = nameBuf.data() + nameAt[r];  // up to the name's NUL
+                source.referenceStart[r] = std::max(k.ref_start, (int32_t)regionStart0);
+                source.referenceEnd[r] = std::min(k.ref_end, (int32_t)regionEnd0);
+                source.numBases[r] = k.n_bases;
+                if (chemistries) {
+                    std::string chem;
+                    if (k.rg_len != 255) {
+                        const std::string id(k.rg, k.rg_len);
+                        for (const auto& g : readGroups)
+                            if (g.first == id) chem = g.second;
+                    }
+                    if (std::find(chemsOf[w].begin(), chemsOf[w].end(), chem) == chemsOf[w].end()) chemsOf[w].push_back(std::move(chem));
                 }
-                if (std::find(chems.begin(), chems.end(), chem) == chems.end()) chems.push_back(std::move(chem));
             }
+        };
+        if (workers == 1) {
+            tables(0);
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned w = 0; w < workers; ++w) pool.emplace_back(tables, w);
+            for (auto& th : pool) th.join();
         }
         if (chemistries)
-            for (const auto& chem : chems)
-                if (std::find(chemistries->begin(), chemistries->end(), chem) == chemistries->end()) chemistries->push_back(chem);
+            for (const auto& part : chemsOf)  // workers own consecutive record ranges: concatenation keeps the order
+                for (const auto& chem : part)
+                    if (std::find(chemistries->begin(), chemistries->end(), chem) == chemistries->end()) chemistries->push_back(chem);
         source.packDevice = [dev](uint32_t packFlags, size_t firstRead, size_t count, const msq_qv_thresholds& thr, msq_packed_dev** out) {
             return msq_bam_pack_device(Msq::Context(), dev->bam, firstRead, count, packFlags, &thr, out);
         };
@@ -611,8 +637,8 @@ struct BamUtils
         };
         if (usedDevice) *usedDevice = true;
         if (std::getenv("MSQ_BAM_TRACE"))
-            std::fprintf(stderr, "BamToReadSourceDevice: map + scan %.2f ms, inflate %.2f, header %.2f, index %.2f, records + names %.2f, source %.2f\n",
-                         1e3 * secs(t0, t1), 1e3 * secs(t1, t2), 1e3 * secs(t2, t3), 1e3 * secs(t3, t4), 1e3 * secs(t4, t5), 1e3 * secs(t5, Clock::now()));
+            std::fprintf(stderr, "BamToReadSourceDevice: map + scan + header %.2f ms, inflate %.2f, index %.2f, records + names %.2f, source %.2f\n",
+                         1e3 * secs(t0, t1), 1e3 * secs(t1, t2), 1e3 * secs(t3, t4), 1e3 * secs(t4, t5), 1e3 * secs(t5, Clock::now()));
         if (timings) {
             timings->read = secs(t0, t1);
             timings->inflate = secs(t1, t2);

@@ -35,6 +35,7 @@
 #include <iostream>
 #include <iterator>
 #include <cstddef>
+#include <chrono>
 #include <cstdint>
 #include <exception>
 #include <functional>
@@ -278,13 +279,16 @@ class MSAByRow  // include/pacbio/data/MSA.h:59-93
 public:
     MSAByRow() = default;
     /// The source must stay alive while Rows() / NameToRow() may still be called for the first time (they decode
-    /// lazily); the counts, CodonsAt and MSAByColumn need nothing from it after construction.
+    /// lazily) and while ReadNames() is used (the names are the source's, not copied); the counts, CodonsAt and
+    /// MSAByColumn need nothing from it after construction.
     MSAByRow(const ReadSource& source, InsertionMode insertions = InsertionMode::None)
     {
         const QvThresholds qv;
         thr_ = msq_qv_thresholds{qv.QualQV, qv.DelQV, qv.SubQV, qv.InsQV};
+        const auto tr0 = std::chrono::steady_clock::now();
         numReads_ = source.names.size();
-        names_ = source.names;
+        sourceNames_ = &source.names;  // not copied (10^5 strings are 7 ms): the source outlives the MSA's use of them, see above
+        const auto tr1 = std::chrono::steady_clock::now();
         const ReadSource* src = &source;
         TakeShare(insertions, [src](size_t k) { return (uint64_t)src->numBases[k]; });
         pack_ = [src](uint32_t packFlags, size_t first, size_t count, const msq_qv_thresholds& thr, msq_packed_dev** dev,
@@ -296,7 +300,13 @@ public:
             for (uint32_t i = 0; i < len; ++i) s[i] = bases[first + i].Nucleotide;
             return s;
         };
-        Finish(PackShare(insertions == InsertionMode::None ? 0u : MSQ_PACK_PLAIN), numReads_ == 0, insertions);
+        msq_packed_dev* packed = PackShare(insertions == InsertionMode::None ? 0u : MSQ_PACK_PLAIN);
+        const auto tr2 = std::chrono::steady_clock::now();
+        Finish(packed, numReads_ == 0, insertions);
+        if (std::getenv("MSQ_BAM_TRACE")) {
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "MSAByRow(ReadSource): names %.2f ms, pack %.2f, bounds + pileup + counts %.2f\n", ms(tr0, tr1), ms(tr1, tr2), ms(tr2, std::chrono::steady_clock::now()));
+        }
     }
     MSAByRow(const std::vector<std::shared_ptr<Data::ArrayRead>>& reads, InsertionMode insertions = InsertionMode::None)
     {
@@ -347,7 +357,7 @@ public:
     const uint32_t* DeviceCodonCounts() const { return dCounts_ ? dCounts_->get() + (size_t)width_ * 6 : nullptr; }
     size_t NumReads() const { return numReads_; }
     /// Names of the reads, in row order (MSARow::Read->Name(), src/MSA.cpp:100-104).
-    const std::vector<std::string>& ReadNames() const { return names_; }
+    const std::vector<std::string>& ReadNames() const { return sourceNames_ ? *sourceNames_ : names_; }
     /// MSARow::CodonAt(pos[k]) of every row, as msq_phase_codons keys: [row][k], three 3-bit symbols each
     /// (0 ' ', 1..4 ACGT, 5 '-', 6 'N', 7 = index left out by CodonAt); src/MSA.cpp:188-195.
     std::vector<uint16_t> PhaseKeys(const std::vector<int32_t>& pos) const
@@ -588,7 +598,7 @@ private:
         }
         for (size_t r = 0; r < n; ++r) {
             if (r < kept_.size()) rows[r]->Read = kept_[r];
-            nameToRow_[names_[r]] = rows[r];  // a later read of the same name takes the entry (src/MSA.cpp:103)
+            nameToRow_[ReadNames()[r]] = rows[r];  // a later read of the same name takes the entry (src/MSA.cpp:103)
         }
         rows_ = std::move(rows);
         materialised_ = true;
@@ -766,6 +776,7 @@ private:
     std::shared_ptr<msq_packed_dev> dev_;  // the packed reads stay in HBM for the phasing pass
     msq_qv_thresholds thr_{-1, -1, -1, -1};
     std::vector<std::string> names_;
+    const std::vector<std::string>* sourceNames_ = nullptr;  // an MSA over a ReadSource reads the source's names
     std::vector<std::map<std::string, int>> insertions_;
     // for Rows(): how to pack the reads again, their literal bases, the reads the rows share, and the rows themselves
     PackFn pack_;

@@ -591,15 +591,15 @@ extern "C" int msq_bam_pack_device(msq_ctx* ctx, const msq_bam_dev* bam, uint64_
             rows.gap[op] = table[(uint8_t)kOps[op] | ((unsigned)(uint8_t)(op == 6 ? '*' : '-') << 8)];
         }
     }
-    void *d_base_off = nullptr, *d_compact = nullptr, *d_presence = nullptr;
-    auto release = [&]() {
-        for (void* p : {d_base_off, d_compact, d_presence})
-            if (p) (void)hipFree(p);
-    };
-    hipError_t e = hipMalloc(&d_base_off, (count + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc(&d_compact, std::max<uint64_t>(total, 64));
-    if (e == hipSuccess) e = hipMalloc(&d_presence, 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_base_off, base_off.data(), (count + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    // the translated bytes, the base offsets and the presence word live in the context's scratch (the file image that
+    // msq_bgzf_inflate_device staged there is long inflated): [0, 256) the packer's own words, then these
+    const uint64_t off_bytes = ((count + 1) * 8 + 255) & ~255ull;
+    void* scratch = nullptr;
+    if (int rc = msq_scratch(ctx, 512 + off_bytes + std::max<uint64_t>(total, 64), &scratch)) return rc;
+    char* const d_presence = (char*)scratch + 256;
+    char* const d_base_off = (char*)scratch + 512;
+    char* const d_compact = d_base_off + off_bytes;
+    hipError_t e = hipMemcpyAsync(d_base_off, base_off.data(), (count + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_presence, 0, 4, ctx->stream);
     uint32_t presence = 0;
     if (e == hipSuccess && count) {
@@ -611,12 +611,10 @@ extern "C" int msq_bam_pack_device(msq_ctx* ctx, const msq_bam_dev* bam, uint64_
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         (void)hipStreamSynchronize(ctx->stream);
-        release();
-        return msq_fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "msq_bam_pack_device: %s", hipGetErrorString(e));
+        return msq_fail(MSQ_ERR_HIP, "msq_bam_pack_device: %s", hipGetErrorString(e));
     }
     const int rc = msq_pack_compact_resident(ctx, count, rs.data(), re.data(), base_off.data(), (const uint64_t*)d_base_off, (const uint8_t*)d_compact,
                                              presence, pack_flags, &thr, out);
-    (void)hipStreamSynchronize(ctx->stream);
-    release();
+    (void)hipStreamSynchronize(ctx->stream);  // the scratch may go to its next user
     return rc;
 }

@@ -342,31 +342,35 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     br.refill();
                     const int K = br.cnt - 15;  // a code that starts at offset <= K has all its bits (and 5 to spare) in buf
                     const uint32_t mine = S.lit[(uint32_t)(br.buf >> lane) & ((1u << LIT_BITS) - 1u)];
-                    // the chain walk, eight scalar instructions per literal (hand-written: the compiler's version of this
-                    // loop took thirteen, and the kernel is bound by instruction issue): starts = the offsets where a
-                    // literal's code starts, k = the offset behind the last one, e = the entry that ended the walk,
-                    // more = the walk ended at the window's end, not at a non-literal
+                    // where the chain goes on from offset `lane`: behind the literal that starts there, or to 64 when the code
+                    // there is no literal (or no code of the primary table)
+                    const uint32_t onward = (mine & kNotLiteral) ? 64u : (uint32_t)lane + (mine & 15u);
+                    // the chain walk, five scalar instructions per literal (hand-written: the compiler's version of this loop
+                    // took thirteen, and the kernel is bound by instruction issue): every offset visited gets its bit in
+                    // `starts`; the walk ends behind the window (k <= 59) or at a non-literal (k = 64, its offset the last bit
+                    // set).  The lane select of v_readlane is written by s_mov, never directly by the v_readlane before it
+                    // (a VALU-written SGPR as lane select needs wait states).
                     uint64_t starts;
-                    int k, more;
+                    int k;
                     uint32_t tmp;
                     asm volatile(
                         "s_mov_b64 %[st], 0\n\t"
-                        "s_mov_b32 %[k], 0\n\t"
-                        "s_mov_b32 %[more], 0\n"
+                        "s_mov_b32 %[k], 0\n"
                         "1:\n\t"
-                        "v_readlane_b32 %[e], %[mine], %[k]\n\t"
-                        "s_bitcmp1_b32 %[e], 15\n\t"
-                        "s_cbranch_scc1 2f\n\t"
                         "s_bitset1_b64 %[st], %[k]\n\t"
-                        "s_and_b32 %[t], %[e], 15\n\t"
-                        "s_add_i32 %[k], %[k], %[t]\n\t"
+                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+                        "s_mov_b32 %[k], %[t]\n\t"
                         "s_cmp_le_i32 %[k], %[K]\n\t"
-                        "s_cbranch_scc1 1b\n\t"
-                        "s_mov_b32 %[more], 1\n"
-                        "2:"
-                        : [st] "=&s"(starts), [k] "=&s"(k), [e] "=&s"(e), [more] "=&s"(more), [t] "=&s"(tmp)
-                        : [mine] "v"(mine), [K] "s"(K)
+                        "s_cbranch_scc1 1b"
+                        : [st] "=&s"(starts), [k] "=&s"(k), [t] "=&s"(tmp)
+                        : [onward] "v"(onward), [K] "s"(K)
                         : "scc");
+                    const bool more = k < 64;
+                    if (!more) {  // the last offset visited holds the non-literal: it is no start of a literal
+                        k = 63 - __builtin_clzll(starts);
+                        starts &= ~(1ull << k);
+                        e = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
+                    }
                     if (starts) {
                         const uint32_t n = (uint32_t)__popcll(starts);
                         if (pos + n > out_len) return INF_ERR_OUTPUT;
@@ -424,9 +428,8 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = src[i % dist];
                 }
                 pos += len;
-                if (br.bit_pos() > end_bit) return INF_ERR_INPUT;
             }
-            if (br.bit_pos() > end_bit) return INF_ERR_INPUT;
+            if (br.bit_pos() > end_bit) return INF_ERR_INPUT;  // checked per block: its symbols are bounded by ISIZE either way
         }
         if (bfinal) break;
     }
@@ -531,7 +534,7 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
     };
     bool ordered = true;  // members in file order (a BGZF file's are): pieces are member ranges
     for (uint64_t m = 1; m < n_members; ++m) ordered = ordered && members[m].in_off >= members[m - 1].in_off;
-    const uint64_t n_pieces = (ordered && file_bytes >= ((uint64_t)32 << 20)) ? std::max<uint64_t>(1, ctx->bam_pieces) : 1;
+    const uint64_t n_pieces = (ordered && file_bytes >= ctx->bam_piece_min_bytes) ? std::max<uint64_t>(1, ctx->bam_pieces) : 1;
     uint64_t copied = 0;  // file bytes on their way
     for (uint64_t m0 = 0, piece = 0; e == hipSuccess && m0 < n_members; ++piece) {
         uint64_t m1 = m0 + 1, upto = file_bytes;

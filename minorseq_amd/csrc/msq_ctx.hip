@@ -75,6 +75,7 @@ extern "C" int msq_debug_tune(msq_ctx* ctx, int key, long long value)
     case MSQ_TUNE_CARRIER_MIN_BATCHES: ctx->carrier_min_batches = (int64_t)value; return MSQ_OK;
     case MSQ_TUNE_NO_HAPS: ctx->no_haps = value != 0; return MSQ_OK;
     case MSQ_TUNE_BAM_PIECES: ctx->bam_pieces = value < 1 ? 1 : (uint64_t)value; return MSQ_OK;
+    case MSQ_TUNE_BAM_PIECE_MIN_BYTES: ctx->bam_piece_min_bytes = value < 0 ? 0 : (uint64_t)value; return MSQ_OK;
     case MSQ_TUNE_BAM_SEGMENT: ctx->bam_segment_bytes = value < 64 ? 64 : (uint64_t)value; return MSQ_OK;
     default: return msq_fail(MSQ_ERR_ARG, "msq_debug_tune: unknown key %d", key);
     }

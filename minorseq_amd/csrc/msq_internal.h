@@ -61,7 +61,8 @@ struct msq_ctx {
     bool no_haps = false;              // MSQ_NO_HAPS / MSQ_TUNE_NO_HAPS: msq_reads_align makes no haplotype groups
     // msq_bgzf_inflate_device: the file image's pieces cross PCIe on copy_stream beside the inflate kernels of the pieces before
     hipStream_t copy_stream = nullptr;
-    uint64_t bam_pieces = 2;             // msq_bgzf_inflate_device: pieces a file of >= 32 MB is uploaded and inflated in
+    uint64_t bam_pieces = 2;             // msq_bgzf_inflate_device: pieces a file of >= bam_piece_min_bytes is uploaded and inflated in
+    uint64_t bam_piece_min_bytes = (uint64_t)32 << 20;
     uint64_t bam_segment_bytes = 16384;  // msq_bam_index_device: the stream is searched for record starts in segments of this size
 };
 

@@ -124,6 +124,16 @@ def test_many_members_and_odd_payload_offsets(ctx):
     want = b"".join(zlib.decompress(blob[m[0]:m[0] + m[2]], -15) for m in members)
     assert inflate_device(ctx, blob, members) == want
     assert len({m[0] & 3 for m in members}) == 4
+    # ... and with the file crossing PCIe in pieces, each piece's members inflated behind its copy (what files of >= 32 MB get)
+    L = abi.lib()
+    try:
+        abi.check(L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECE_MIN_BYTES, 0))
+        for pieces in (2, 3, 7):
+            abi.check(L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, pieces))
+            assert inflate_device(ctx, blob, members) == want
+    finally:
+        L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECE_MIN_BYTES, 32 << 20)
+        L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, 2)
 
 
 def test_bam_shaped_members(ctx, tmp_path):
