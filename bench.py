@@ -77,6 +77,10 @@ def parse():
                     "<= 4096); narrower than the window: partition even a window that fits one slab")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: create the library's RCCL communicator and "
                     "issue the step's collectives even with one rank")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true", help="N > 1 on a box with ONE GPU: every rank uses cuda:0 and the "
+                    "exchange runs over torch.distributed's gloo group (host copies).  Exercises the launcher, the shards, the "
+                    "collective call sites, verification and the JSON line of an N > 1 run; its numbers are NOT a measurement "
+                    "(the ranks share one GPU) and the line says so")
     ap.add_argument("--exchange", default="lib", choices=["lib", "torch"], help="N > 1: the library's RCCL communicator "
                     "(msq_comm_*) or, for comparison, torch.distributed's RCCL group (also the fallback when the "
                     "library communicator cannot be made; the line's config.exchange says which ran)")
@@ -453,6 +457,9 @@ def main():
         sys.exit(launch(a))
     if a.launch_dry_run:
         raise SystemExit("--launch-dry-run describes the launcher of a plain `python bench.py --gpus N` with N > 1")
+    if os.environ.get("MSQ_BENCH_WATCHDOG"):  # debugging aid: every thread's stack to stderr, then exit, after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MSQ_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -477,7 +484,12 @@ def main():
     from minorseq_amd import abi, device, sharding, synth
 
     n_dev = torch.cuda.device_count()  # counting does not initialise the GPU
-    if n_dev <= local or n_dev < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+    shared = bool(a.rehearse_shared_gpu) and world > 1
+    if shared:
+        if n_dev < 1:
+            raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+        local = 0  # every rank on the box's one GPU
+    elif n_dev <= local or n_dev < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
         raise SystemExit("bench.py --gpus %d needs %d GPUs, found %d" % (a.gpus, a.gpus, n_dev))
     multi = world > 1 or a.force_dist
     if world > 1:
@@ -495,7 +507,24 @@ def main():
     torch.cuda.set_device(local)
     ctx = device.Ctx(local)
     ex_note = None
-    if world > 1:
+    if shared:
+        class _SharedGpuExchange(sharding.TorchExchange):  # device tensors go through the host by hand (gloo's own CUDA path hung here)
+            def allreduce_bounds_device(self, bounds):
+                h = bounds.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX)
+                bounds.copy_(h)
+                return bounds
+
+            def allreduce_counts(self, counts):
+                h = counts.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                counts.copy_(h)
+                return counts
+        ex = _SharedGpuExchange(None)
+        ex_note = ("REHEARSAL, not a measurement: %d ranks share cuda:0, bounds MAX + counts SUM over torch.distributed's gloo group "
+                   "(host copies); RCCL is not in this run" % world)
+        print("bench: " + ex_note, file=sys.stderr)
+    elif world > 1:
         # every rank must take the same road.  msq_comm_create is a collective (ncclCommInitRank): a rank that cannot
         # even load RCCL must say so BEFORE the others enter it, so the ranks first agree on a local, non-collective
         # check (msq_comm_available) and only then create the communicator; if any of them cannot, all of them take
@@ -561,6 +590,13 @@ def main():
     primary = measure(a.scaling)
     run, total, dt, kernel_ms, path_ms, timed_steps, verified = primary
     secondary = None
+
+    class _RunFacts:  # what the JSON line says about the primary run, kept when the run itself makes room for the next
+        def __init__(self, r):
+            self.aligned, self.align_ms = r.aligned, getattr(r, "align_ms", 0.0)
+            self.has_gcol, self.hap_count = bool(r.dr.view.gcol), int(r.dr.view.hap_count)
+            self.launches_per_step, self.spinup_steps = r.launches_per_step, r.spinup_steps
+    facts = _RunFacts(run)
     if world > 1 and a.scaling == "weak":  # the strong-scaling measurement of the same run, carried along
         keep = (run.n_bases, run.W, run.plan.P, int(run.plan.n_tests.item()), run.baked, run.flow, run.part.n_slabs if run.part else None,
                 run.deviation_share(), run.reads)
@@ -665,9 +701,9 @@ def main():
         # what the kernel really streams: 16 B of bit planes per 32-base group, 32 B per group for every QV plane a
         # threshold makes it read, 12 B of tables per read (the QV planes of an unmasked or baked set are never touched)
         # + 4 B per group of column index when the set carries one and the kernel variant uses it (no QV planes to read)
-        aligned = run.aligned
-        indexed = (not aligned) and bool(run.dr.view.gcol) and (baked or planes == 0) and a.mode != "simple"
-        groups = int(run.dr.view.hap_count) if aligned else 0  # haplotype groups: + 4 B/read of the group-ordered read list
+        aligned = facts.aligned
+        indexed = (not aligned) and facts.has_gcol and (baked or planes == 0) and a.mode != "simple"
+        groups = facts.hap_count if aligned else 0  # haplotype groups: + 4 B/read of the group-ordered read list
         per_read = (24.0 if groups >= 2 else 20.0) if aligned else 12.0
         real_bytes = n_bases / 32 * (16 + 32 * (0 if (baked or aligned) else planes) + (4 if indexed else 0)) + per_read * shard_reads
         kernel_name = "pileup_simple_kernel" if a.mode == "simple" else "pileup_rows_kernel" if aligned else "pileup_kernel"
@@ -707,13 +743,13 @@ def main():
                 "exchange": (ex_note or (("one RCCL group per step (bounds MAX + counts SUM)" if flow == "known" else "two RCCL all-reduces per step")
                                           + ", library communicator (msq_comm_*) of %d rank%s as RCCL reports it" % (comm_ranks, "" if comm_ranks == 1 else "s")))
                             if multi else "none (one GPU)",
-                "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 125) // 126 if run.aligned else (((W + 31) // 32) + 127) // 128),
-                "pileup_launches_per_step": run.launches_per_step,
+                "column_slabs": (n_slabs if n_slabs else (((W + 31) // 32) + 125) // 126 if facts.aligned else (((W + 31) // 32) + 127) // 128),
+                "pileup_launches_per_step": facts.launches_per_step,
                 "read_layout": ("column-slab partition (built at set-up)" if n_slabs else
-                                "one read set, column-aligned (msq_reads_align at set-up: %.1f ms; %s)" % (run.align_ms, "%d haplotype groups" % groups if groups >= 2 else "one population") if aligned else "one read set, normalized groups"),
+                                "one read set, column-aligned (msq_reads_align at set-up: %.1f ms; %s)" % (facts.align_ms, "%d haplotype groups" % groups if groups >= 2 else "one population") if aligned else "one read set, normalized groups"),
                 "qv_thresholds": "unset" if a.qualqv < 0 and not a.rich else "applied at pack time (baked; the bake pass is set-up, not timed)" if baked else "applied in every pass",
-                "clock_spinup": ("%d untimed steps (%.0f ms) at the end of set-up, before the warm-up steps" % (run.spinup_steps, a.spinup_ms)
-                                 if run.spinup_steps else "none"),
+                "clock_spinup": ("%d untimed steps (%.0f ms) at the end of set-up, before the warm-up steps" % (facts.spinup_steps, a.spinup_ms)
+                                 if facts.spinup_steps else "none"),
                 "bases_per_gpu": int(n_bases), "codon_positions": P, "number_of_tests": n_tests,
                 "bases_off_majority": dev_share},
             # `bound` says what limits the kernel ("hbm" from 80 % of what a device copy reaches on this part, 6.3 TB/s,
@@ -744,6 +780,8 @@ def main():
             out["strong_projection"] = projection
         if compare is not None:
             out["read_space_kernel"] = compare
+        if shared:
+            out["rehearsal"] = "ranks share one GPU, exchange over gloo: control flow only, `value` is not a measurement"
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     ex.close()
