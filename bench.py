@@ -78,8 +78,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: create the library's RCCL communicator and "
                     "issue the step's collectives even with one rank")
     ap.add_argument("--rehearse-shared-gpu", action="store_true", help="N > 1 on a box with ONE GPU: every rank uses cuda:0 and the "
-                    "exchange runs over torch.distributed's gloo group (host copies).  Exercises the launcher, the shards, the "
-                    "collective call sites, verification and the JSON line of an N > 1 run; its numbers are NOT a measurement "
+                    "exchange runs through the library communicator's shared-memory rehearsal transport (MSQ_COMM_TRANSPORT=shm, "
+                    "host copies).  Exercises the launcher, the shards, the msq_comm_* call sites, verification and the JSON "
+                    "line of an N > 1 run; its numbers are NOT a measurement "
                     "(the ranks share one GPU) and the line says so")
     ap.add_argument("--exchange", default="lib", choices=["lib", "torch"], help="N > 1: the library's RCCL communicator "
                     "(msq_comm_*) or, for comparison, torch.distributed's RCCL group (also the fallback when the "
@@ -508,21 +509,12 @@ def main():
     ctx = device.Ctx(local)
     ex_note = None
     if shared:
-        class _SharedGpuExchange(sharding.TorchExchange):  # device tensors go through the host by hand (gloo's own CUDA path hung here)
-            def allreduce_bounds_device(self, bounds):
-                h = bounds.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.MAX)
-                bounds.copy_(h)
-                return bounds
-
-            def allreduce_counts(self, counts):
-                h = counts.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM)
-                counts.copy_(h)
-                return counts
-        ex = _SharedGpuExchange(None)
-        ex_note = ("REHEARSAL, not a measurement: %d ranks share cuda:0, bounds MAX + counts SUM over torch.distributed's gloo group "
-                   "(host copies); RCCL is not in this run" % world)
+        # the library's own communicator and entry points (msq_comm_*), over its shared-memory rehearsal transport: RCCL
+        # refuses ranks that share a device
+        os.environ["MSQ_COMM_TRANSPORT"] = "shm"
+        ex = sharding.LibExchange(ctx, rank, world, sharding.torch_bootstrap)
+        ex_note = ("REHEARSAL, not a measurement: %d ranks share cuda:0; bounds MAX + counts SUM through the library communicator "
+                   "(msq_comm_*) over its shared-memory rehearsal transport (host copies); RCCL and xGMI are not in this run" % world)
         print("bench: " + ex_note, file=sys.stderr)
     elif world > 1:
         # every rank must take the same road.  msq_comm_create is a collective (ncclCommInitRank): a rank that cannot
@@ -781,7 +773,7 @@ def main():
         if compare is not None:
             out["read_space_kernel"] = compare
         if shared:
-            out["rehearsal"] = "ranks share one GPU, exchange over gloo: control flow only, `value` is not a measurement"
+            out["rehearsal"] = "ranks share one GPU, exchange over host shared memory: control flow only, `value` is not a measurement"
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     ex.close()

@@ -405,6 +405,10 @@ int msq_timing_read_path(msq_ctx* ctx, float* ms_out, int32_t capacity, int32_t*
  * of one sample are sharded over the GPUs of a node, one process (and one context) per GPU -- RCCL collectives
  * over xGMI on the context's stream.  Counts are additive integers and the window is a min / max, so every rank
  * ends up with bit-identical matrices and the testing pass (msq_call_cells) runs replicated, with no broadcast.
+ * Rehearsal transport: with MSQ_COMM_TRANSPORT=shm in the environment (when the id is made and the communicator
+ * created) the same entry points exchange through a POSIX shared-memory segment between processes of one host that may
+ * share ONE GPU -- which RCCL refuses -- host-synchronously.  It exists so that a one-GPU box can run world > 1 (the
+ * sharded C++ front, the bench's ranks, tests/test_gpu_comm.py); it is no data path and nothing else selects it.
  *   rank 0:      msq_comm_unique_id(id)            -> hand the 128 bytes to every rank (MPI, a file, any store)
  *   every rank:  msq_comm_create(ctx, rank, world, id)
  *   per step:    msq_window_bounds_device -> msq_comm_allreduce_bounds -> msq_pileup_device_window (own shard)

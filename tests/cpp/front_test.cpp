@@ -155,10 +155,25 @@ int main()
     // MSQ_TEST_COMM=1: the same run as the one rank of a "sharded" sample -- the library's RCCL communicator, the
     // share rule, the bounds / count all-reduces and the all-gather of the phasing keys are all on the path, and
     // every line of the dump must be what the plain run prints
-    if (std::getenv("MSQ_TEST_COMM")) {
-        uint8_t id[MSQ_COMM_ID_BYTES];
-        Msq::Check(msq_comm_unique_id(id));
-        Msq::SetCommunicator(0, 1, id);
+    // MSQ_TEST_COMM=<rank>/<world> with MSQ_TEST_COMM_ID=<hex of the communicator id> (and MSQ_COMM_TRANSPORT=shm on a box
+    // with one GPU): one of several processes that share the sample -- EVERY rank must print the plain run's dump
+    if (const char* spec = std::getenv("MSQ_TEST_COMM")) {
+        uint8_t id[MSQ_COMM_ID_BYTES] = {0};
+        int rank = 0, world = 1;
+        if (std::sscanf(spec, "%d/%d", &rank, &world) == 2) {
+            const char* hex = std::getenv("MSQ_TEST_COMM_ID");
+            if (!hex) throw std::runtime_error("MSQ_TEST_COMM=<rank>/<world> needs MSQ_TEST_COMM_ID");
+            for (size_t k = 0; k < MSQ_COMM_ID_BYTES && hex[2 * k] && hex[2 * k + 1]; ++k) {
+                unsigned v = 0;
+                std::sscanf(hex + 2 * k, "%2x", &v);
+                id[k] = (uint8_t)v;
+            }
+        } else {
+            rank = 0;
+            world = 1;
+            Msq::Check(msq_comm_unique_id(id));
+        }
+        Msq::SetCommunicator(rank, world, id);
         std::fprintf(stderr, "communicator: rank %d of %d\n", Msq::CommRank(), Msq::CommWorld());
     }
     // FisherTest.EquivalentWithR

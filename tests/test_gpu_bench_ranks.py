@@ -1,5 +1,5 @@
 """bench.py's N > 1 control flow on the one-GPU box: `--rehearse-shared-gpu` puts every rank on cuda:0 and moves the
-exchange over gloo, so the launcher (bench.py starting its own ranks), the rank processes under torch.distributed.run,
+exchange through the library communicator's shared-memory rehearsal transport, so the launcher (bench.py starting its own ranks), the rank processes under torch.distributed.run,
 the weak and the carried strong measurement, verification against the simple kernel and the assembly of the ONE JSON
 line all run -- everything of an 8-GPU run but RCCL and xGMI (those: tests/test_gpu_comm.py with one rank).  Its first run
 found the weak-scaling line referencing a run it had already freed: the command the driver issues for N > 1 crashed."""

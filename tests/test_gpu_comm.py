@@ -3,6 +3,7 @@ offers: the communicator comes up from its 128-byte id, every collective leaves 
 whole sharded step (prologue -> pileup -> one RCCL group -> testing pass) equals the plain calls, and the shard
 rule partitions the reads.  The N = 2 arithmetic is covered on CPU (tests/test_sharding_gloo.py)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -131,3 +132,23 @@ def test_shard_rule_matches_the_library():
                 assert (f.value, c.value) == sharding.shard_range(n, r, world) and f.value == nxt
                 nxt += c.value
             assert nxt == n
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_entry_points_with_several_ranks_over_the_rehearsal_transport(world, tmp_path):
+    """msq_comm_* with world > 1 on the one-GPU box: `world` processes, MSQ_COMM_TRANSPORT=shm (RCCL refuses ranks that share a
+    GPU; the transport is the library's own, behind the same entry points) -- bounds MAX, counts SUM beyond one transfer
+    slot, the step's group, all-gather in rank order, the agreed status of a run in which two ranks fail
+    (tests/comm_worker.py).  What stays untested without a multi-GPU node is RCCL itself."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MSQ_COMM_TRANSPORT="shm")
+    ident = os.urandom(16).hex()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "comm_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), ident], env=env, stdout=open(tmp_path / ("out%d" % r), "w"),
+                              stderr=open(tmp_path / ("err%d" % r), "w")) for r in range(world)]
+    for p in procs:
+        p.wait(timeout=280)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, open(tmp_path / ("err%d" % r)).read()[-2000:]
+        assert ("OK rank %d of %d" % (r, world)) in open(tmp_path / ("out%d" % r)).read()

@@ -134,6 +134,38 @@ def test_one_rank_communicator_changes_nothing():
     assert keep(comm.stdout) == keep(plain.stdout) and len(plain.stdout) > 100000
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_front_with_several_ranks_prints_the_plain_dump_on_every_rank(world):
+    """The C++ front with world > 1 on the one-GPU box: `world` processes share the sample (Msq::SetCommunicator), each
+    piles up its share, bounds and counts are all-reduced, phasing keys all-gathered (padded shares laid out in read
+    order), statuses agreed before any rank throws -- through the library's own msq_comm_* entry points, over the
+    shared-memory rehearsal transport (MSQ_COMM_TRANSPORT=shm: RCCL refuses ranks that share a GPU).  Every rank must
+    print, line for line, what the plain single-process run prints: matrices, calls, haplotypes, reports, exceptions."""
+    env = dict(os.environ)
+    for k in ("DELQV", "SUBQV", "INSQV", "QUALQV"):
+        env.pop(k, None)
+    import tempfile
+    with tempfile.TemporaryDirectory() as cwd:
+        plain = subprocess.run([BIN], capture_output=True, text=True, timeout=300, env=env, cwd=cwd)
+        assert plain.returncode == 0
+        env["MSQ_COMM_TRANSPORT"] = "shm"
+        env["MSQ_TEST_COMM_ID"] = os.urandom(16).hex()
+        procs = []
+        for r in range(world):
+            e = dict(env, MSQ_TEST_COMM="%d/%d" % (r, world))
+            d = os.path.join(cwd, "rank%d" % r)
+            os.mkdir(d)
+            # into files: a rank blocked on a full pipe never reaches the next collective, and the others wait for it there
+            procs.append(subprocess.Popen([BIN], stdout=open(os.path.join(d, "out"), "w"), stderr=open(os.path.join(d, "err"), "w"), env=e, cwd=d))
+        for p in procs:
+            p.wait(timeout=280)
+        outs = [(open(os.path.join(cwd, "rank%d" % r, "out")).read(), open(os.path.join(cwd, "rank%d" % r, "err")).read()) for r in range(world)]
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (r, err[-2000:])
+        assert "communicator: rank %d of %d" % (r, world) in err
+        assert out.splitlines() == plain.stdout.splitlines(), r
+
+
 def to_reads(recs, rich):
     rows = []
     for start, end, cig, nuc, qs in recs:
