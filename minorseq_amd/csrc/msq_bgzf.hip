@@ -539,7 +539,9 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
     for (uint64_t m0 = 0, piece = 0; e == hipSuccess && m0 < n_members; ++piece) {
         uint64_t m1 = m0 + 1, upto = file_bytes;
         if (piece + 1 < n_pieces) {  // up to the member that crosses this piece's share of the file
-            const uint64_t share = file_bytes / n_pieces * (piece + 1);
+            // the last piece is twice the size of the others: its kernel has no copy to wait for, and a kernel costs ~6 ms
+            // however small its piece (first_share_pct: experiments)
+            const uint64_t share = n_pieces == 2 ? file_bytes / 100 * ctx->bam_first_share_pct : file_bytes / (n_pieces + 1) * (piece + 1);
             while (m1 < n_members && members[m1 - 1].in_off + members[m1 - 1].in_len < share) ++m1;
             upto = members[m1 - 1].in_off + members[m1 - 1].in_len;
         } else {

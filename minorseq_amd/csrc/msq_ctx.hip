@@ -61,6 +61,7 @@ extern "C" int msq_ctx_create(int device, msq_ctx** out)
     }
     c->no_merge = std::getenv("MSQ_NO_MERGE") != nullptr;
     c->no_haps = std::getenv("MSQ_NO_HAPS") != nullptr;
+    if (const char* v = std::getenv("MSQ_BAM_FIRST_SHARE")) c->bam_first_share_pct = (uint64_t)std::min(99ll, std::max(1ll, strtoll(v, nullptr, 10)));
     if (const char* v = std::getenv("MSQ_BAM_PIECES")) c->bam_pieces = (uint64_t)std::max(1ll, strtoll(v, nullptr, 10));
     if (const char* v = std::getenv("MSQ_CARRIER_MIN_BATCHES")) c->carrier_min_batches = (int64_t)strtoll(v, nullptr, 10);
     *out = c;

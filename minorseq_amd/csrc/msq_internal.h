@@ -63,6 +63,7 @@ struct msq_ctx {
     hipStream_t copy_stream = nullptr;
     uint64_t bam_pieces = 2;             // msq_bgzf_inflate_device: pieces a file of >= bam_piece_min_bytes is uploaded and inflated in
     uint64_t bam_piece_min_bytes = (uint64_t)32 << 20;
+    uint64_t bam_first_share_pct = 33;   // two pieces: the first one's share of the file
     uint64_t bam_segment_bytes = 16384;  // msq_bam_index_device: the stream is searched for record starts in segments of this size
 };
 
