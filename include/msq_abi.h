@@ -510,6 +510,12 @@ typedef struct msq_bam_dev msq_bam_dev; /* a BAM file's inflated stream (and, af
 /* host arrays in (the file image may be a pageable mapping); synchronises.  zlib's inflate of every member, bit for bit. */
 int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64_t file_bytes, const msq_bgzf_member* members,
                             uint64_t n_members, msq_bam_dev** out);
+/* Optional, ahead of msq_bgzf_inflate_device on the same (file, file_bytes): start the file image's way to the device
+ * and return at once (the copies are issued by a thread of the library's own: a copy from a pageable mapping blocks its
+ * thread).  The caller scans the BGZF headers meanwhile; the inflate call finds the image staged and launches every
+ * piece's members as that piece gets on its way.  The file must stay mapped until the inflate call has returned or
+ * msq_bgzf_stage_file(ctx, NULL, 0) has forgotten the image.  No other call on the context in between. */
+int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t file_bytes);
 uint64_t msq_bam_dev_bytes(const msq_bam_dev* bam);
 /* bytes [off, off + len) of the inflated stream to the host (the BAM header; tests); synchronises */
 int msq_bam_dev_read(msq_ctx* ctx, const msq_bam_dev* bam, uint64_t off, uint64_t len, void* host_dst);

@@ -162,6 +162,7 @@ _SIGNATURES = {
     "msq_pileup_check": (C.c_int, [_P]),
     "msq_rows_decode": (C.c_int, [_P, C.POINTER(PackedReads), C.POINTER(QvThresholds), C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, _P]),
     "msq_bgzf_inflate_device": (C.c_int, [_P, _P, C.c_uint64, _P, C.c_uint64, C.POINTER(_P)]),
+    "msq_bgzf_stage_file": (C.c_int, [_P, _P, C.c_uint64]),
     "msq_bam_dev_bytes": (C.c_uint64, [_P]),
     "msq_bam_dev_read": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, _P]),
     "msq_bam_dev_free": (C.c_int, [_P, _P]),

@@ -495,6 +495,15 @@ struct BamUtils
         {
             const MappedFile file(filePath);
             fileBytes = file.size();
+            // the file image starts on its way to the GPU (the library's copy thread) while this thread scans the BGZF
+            // headers and reads the BAM header; whatever happens here, an image nobody will use is forgotten before the
+            // mapping goes
+            struct Staging
+            {
+                msq_ctx* ctx;
+                ~Staging() { (void)msq_bgzf_stage_file(ctx, nullptr, 0); }  // nothing to forget once the inflate call has taken it
+            } staging{ctx};
+            if (file.size()) (void)msq_bgzf_stage_file(ctx, file.data(), file.size());  // an error repeats in the inflate call
             const std::vector<BgzfBlock> blocks = ScanBgzf(file, &bamBytes);
             std::vector<msq_bgzf_member> members(blocks.size());
             for (size_t b = 0; b < blocks.size(); ++b)

@@ -475,10 +475,11 @@ extern "C" int msq_bam_index_device(msq_ctx* ctx, msq_bam_dev* bam, uint64_t fir
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) return hip_fail("record kernel", e);
             t_records = ms_since();
-            bam->h_kept.reserve(total);
+            uint64_t n_keep = 0;
             for (uint64_t r = 0; r < total; ++r) {
                 const msq_bam_record& k = all[r];
                 if (k.status == MSQ_BAM_REC_SKIP) continue;
+                ++n_keep;
                 if (k.status != MSQ_BAM_REC_KEEP) {
                     release();
                     return msq_fail(MSQ_ERR_DATA, k.status == MSQ_BAM_REC_MALFORMED ? "malformed BAM record (record %llu)"
@@ -486,7 +487,13 @@ extern "C" int msq_bam_index_device(msq_ctx* ctx, msq_bam_dev* bam, uint64_t fir
                                                                                     : "Unexpected cigar (record %llu)",
                                     (unsigned long long)r);
                 }
-                bam->h_kept.push_back(k);
+            }
+            if (n_keep == total) {  // the table as it came back is the kept table: no second copy of it
+                bam->h_kept = std::move(all);
+            } else {
+                bam->h_kept.reserve(n_keep);
+                for (uint64_t r = 0; r < total; ++r)
+                    if (all[r].status == MSQ_BAM_REC_KEEP) bam->h_kept.push_back(all[r]);
             }
             if (bam->h_kept.size() == total) {  // every record kept: the table in HBM is the kept table
                 bam->d_kept = bam->d_rec;

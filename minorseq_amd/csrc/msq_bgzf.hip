@@ -26,7 +26,10 @@
 #include <algorithm>
 #include <chrono>
 #include <new>
+#include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 #include "msq_bam_dev.h"
 
@@ -236,8 +239,16 @@ __device__ inline uint32_t decode_sym(uint64_t buf, const uint16_t* table, const
     return uni(long_sym<TBITS>((uint32_t)buf, sorted, cs));
 }
 
+// A member that cannot be inflated ends its wave on the spot (status word, s_endpgm): with plain returns out of the nested
+// loops the compiler threads an exit code through every loop level, and the kernel is bound by instruction issue.
+#define INF_FAIL(code)                       \
+    do {                                     \
+        if (lane == 0) *status = (code);     \
+        __builtin_amdgcn_endpgm();           \
+    } while (0)
+
 __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t file_words, const msq_bgzf_member mem,
-                                   uint8_t* __restrict__ out, WaveLds& S, int lane)
+                                   uint8_t* __restrict__ out, WaveLds& S, int lane, uint32_t* __restrict__ status)
 {
     if (mem.out_len == 0) return INF_OK;  // the end-of-file marker and other empty members: nothing to write
     const uint8_t* file8 = reinterpret_cast<const uint8_t*>(file32);
@@ -253,18 +264,18 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
     bool fixed_ready = false;
     const uint64_t below = (1ull << lane) - 1ull;
     for (;;) {
-        if (br.bit_pos() + 3 > end_bit) return INF_ERR_INPUT;
+        if (br.bit_pos() + 3 > end_bit) INF_FAIL(INF_ERR_INPUT);
         br.refill();
         const uint32_t bfinal = br.bits(1), btype = br.bits(2);
-        if (btype == 3) return INF_ERR_BTYPE;
+        if (btype == 3) INF_FAIL(INF_ERR_BTYPE);
         if (btype == 0) {
             br.drop(br.cnt & 7);  // to the byte boundary
             br.refill();
             const uint32_t len = br.bits(16), nlen = br.bits(16);
-            if ((len ^ 0xffffu) != nlen) return INF_ERR_STORED;
+            if ((len ^ 0xffffu) != nlen) INF_FAIL(INF_ERR_STORED);
             const uint64_t byte = br.bit_pos() >> 3;
-            if ((byte + len) * 8 > end_bit) return INF_ERR_INPUT;
-            if (pos + len > out_len) return INF_ERR_OUTPUT;
+            if ((byte + len) * 8 > end_bit) INF_FAIL(INF_ERR_INPUT);
+            if (pos + len > out_len) INF_FAIL(INF_ERR_OUTPUT);
             for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = file8[byte + i];
             pos += len;
             br.init(byte + len);
@@ -282,7 +293,7 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 n_lit = (int)br.bits(5) + 257;
                 n_dist = (int)br.bits(5) + 1;
                 const int n_cl = (int)br.bits(4) + 4;
-                if (n_lit > 286 || n_dist > 30) return INF_ERR_COUNTS;
+                if (n_lit > 286 || n_dist > 30) INF_FAIL(INF_ERR_COUNTS);
                 if (lane < 19) S.cl_lens[lane] = 0;
                 WAVE_SYNC();
                 for (int i = 0; i < n_cl; ++i) {
@@ -291,15 +302,15 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     if (lane == 0) S.cl_lens[kClOrder[i]] = (uint8_t)v;
                 }
                 WAVE_SYNC();
-                if (const uint32_t e = uni(build_code<CL_BITS>(S.cl_lens, 19, S.cl, S.sorted_cl, &S.cs_cl, S.cnt, false, lane))) return e;
+                if (const uint32_t e = uni(build_code<CL_BITS>(S.cl_lens, 19, S.cl, S.sorted_cl, &S.cs_cl, S.cnt, false, lane))) INF_FAIL(e);
                 const int total = n_lit + n_dist;
                 int i = 0;
                 uint32_t prev = 0;
                 while (i < total) {
-                    if (br.bit_pos() > end_bit) return INF_ERR_INPUT;
+                    if (br.bit_pos() > end_bit) INF_FAIL(INF_ERR_INPUT);
                     br.refill();
                     const uint32_t e = decode_sym<CL_BITS>(br.buf, S.cl, S.sorted_cl, &S.cs_cl);
-                    if (!e) return INF_ERR_SYMBOL;
+                    if (!e) INF_FAIL(INF_ERR_SYMBOL);
                     br.drop((int)(e & 15u));
                     const uint32_t sym = e >> 4;
                     if (sym < 16) {
@@ -311,7 +322,7 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     uint32_t v = 0;
                     int rep;
                     if (sym == 16) {
-                        if (i == 0) return INF_ERR_REPEAT;
+                        if (i == 0) INF_FAIL(INF_ERR_REPEAT);
                         v = prev;
                         rep = 3 + (int)br.bits(2);
                     } else if (sym == 17) {
@@ -321,16 +332,16 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                         rep = 11 + (int)br.bits(7);
                         prev = 0;
                     }
-                    if (i + rep > total) return INF_ERR_REPEAT;
+                    if (i + rep > total) INF_FAIL(INF_ERR_REPEAT);
                     for (int k = lane; k < rep; k += 64) S.lens[i + k] = (uint8_t)v;
                     i += rep;
                 }
                 WAVE_SYNC();
-                if (uni(S.lens[256]) == 0) return INF_ERR_NOEOB;
+                if (uni(S.lens[256]) == 0) INF_FAIL(INF_ERR_NOEOB);
             }
             if (btype == 2 || !fixed_ready) {
-                if (const uint32_t e = uni(build_code<LIT_BITS>(S.lens, n_lit, S.lit, S.sorted_lit, &S.cs_lit, S.cnt, true, lane))) return e;
-                if (const uint32_t e = uni(build_code<DIST_BITS>(S.lens + n_lit, n_dist, S.dist, S.sorted_dist, &S.cs_dist, S.cnt, true, lane))) return e;
+                if (const uint32_t e = uni(build_code<LIT_BITS>(S.lens, n_lit, S.lit, S.sorted_lit, &S.cs_lit, S.cnt, true, lane))) INF_FAIL(e);
+                if (const uint32_t e = uni(build_code<DIST_BITS>(S.lens + n_lit, n_dist, S.dist, S.sorted_dist, &S.cs_dist, S.cnt, true, lane))) INF_FAIL(e);
                 fixed_ready = btype == 1;
             }
             for (;;) {
@@ -373,7 +384,7 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     }
                     if (starts) {
                         const uint32_t n = (uint32_t)__popcll(starts);
-                        if (pos + n > out_len) return INF_ERR_OUTPUT;
+                        if (pos + n > out_len) INF_FAIL(INF_ERR_OUTPUT);
                         if ((starts >> lane) & 1ull) dst[pos + (uint32_t)__popcll(starts & below)] = (uint8_t)(mine >> 4);
                         pos += n;
                     }
@@ -384,18 +395,18 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 e &= ~kNotLiteral;
                 if ((e & 15u) == 0) {
                     e = uni(long_sym<LIT_BITS>((uint32_t)br.buf, S.sorted_lit, &S.cs_lit));
-                    if (!e) return INF_ERR_SYMBOL;
+                    if (!e) INF_FAIL(INF_ERR_SYMBOL);
                 }
                 br.drop((int)(e & 15u));
                 const uint32_t sym = e >> 4;
                 if (sym < 256) {  // a literal with a long code
-                    if (pos >= out_len) return INF_ERR_OUTPUT;
+                    if (pos >= out_len) INF_FAIL(INF_ERR_OUTPUT);
                     if (lane == 0) dst[pos] = (uint8_t)sym;
                     ++pos;
                     continue;
                 }
                 if (sym == 256) break;
-                if (sym > 285) return INF_ERR_SYMBOL;
+                if (sym > 285) INF_FAIL(INF_ERR_SYMBOL);
                 uint32_t len;
                 if (sym < 265) {
                     len = sym - 254;
@@ -407,10 +418,10 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 }
                 br.refill();
                 const uint32_t de = decode_sym<DIST_BITS>(br.buf, S.dist, S.sorted_dist, &S.cs_dist);
-                if (!de) return INF_ERR_SYMBOL;
+                if (!de) INF_FAIL(INF_ERR_SYMBOL);
                 br.drop((int)(de & 15u));
                 const uint32_t dsym = de >> 4;
-                if (dsym > 29) return INF_ERR_DIST;
+                if (dsym > 29) INF_FAIL(INF_ERR_DIST);
                 uint32_t dist;
                 if (dsym < 4) {
                     dist = dsym + 1;
@@ -418,8 +429,8 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     const int xb = (int)(dsym >> 1) - 1;
                     dist = ((2u + (dsym & 1u)) << xb) + 1u + br.bits(xb);
                 }
-                if (dist > pos) return INF_ERR_DIST;
-                if (pos + len > out_len) return INF_ERR_OUTPUT;
+                if (dist > pos) INF_FAIL(INF_ERR_DIST);
+                if (pos + len > out_len) INF_FAIL(INF_ERR_OUTPUT);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the copy reads what this wave has stored
                 const uint8_t* src = dst + (pos - dist);
                 if (dist >= len) {
@@ -429,11 +440,11 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 }
                 pos += len;
             }
-            if (br.bit_pos() > end_bit) return INF_ERR_INPUT;  // checked per block: its symbols are bounded by ISIZE either way
+            if (br.bit_pos() > end_bit) INF_FAIL(INF_ERR_INPUT);  // checked per block: its symbols are bounded by ISIZE either way
         }
         if (bfinal) break;
     }
-    if (pos != out_len) return INF_ERR_SHORT;
+    if (pos != out_len) INF_FAIL(INF_ERR_SHORT);
     return INF_OK;
 }
 
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint32_t* __res
     const uint32_t wave = uni(threadIdx.x >> 6);
     const uint32_t m = blockIdx.x * 4u + wave;
     if (m >= n_members) return;
-    const uint32_t err = inflate_member(file32, file_words, members[m], out, lds[wave], lane);
+    const uint32_t err = inflate_member(file32, file_words, members[m], out, lds[wave], lane, status + m);
     if (lane == 0) status[m] = err;
 }
 
@@ -460,6 +471,84 @@ static void free_bam_dev(msq_bam_dev* b)
     delete b;
 }
 
+// forget a staged image: its copy thread joined, its events destroyed (msq_ctx_destroy calls it too)
+void msq_bgzf_drop_staged(msq_ctx* ctx)
+{
+    if (ctx->stage_thread) {
+        if (ctx->stage_thread->joinable()) ctx->stage_thread->join();
+        delete ctx->stage_thread;
+        ctx->stage_thread = nullptr;
+    }
+    if (ctx->staged_total && ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (int k = 0; k < ctx->staged_total; ++k)
+        if (ctx->staged_event[k]) (void)hipEventDestroy(ctx->staged_event[k]);
+    ctx->staged_total = 0;
+    ctx->staged_done.store(0);
+    ctx->staged_err.store(0);
+    ctx->staged_file = nullptr;
+    ctx->staged_bytes = 0;
+}
+
+// The file image on its way into the context's scratch: pieces on the copy stream, an event behind each.  The copy of a
+// pageable mapping keeps its thread busy (and faults the mapping's pages in), so it runs on a thread of the library's own
+// and this call returns at once: the caller scans the BGZF headers meanwhile, and msq_bgzf_inflate_device launches every
+// piece's kernel as soon as that piece is on its way (it stages the image itself when nobody has).
+// Two pieces, the first a third of the file: a kernel takes ~6 ms however few members it has (one member is one wave,
+// ~14 000 dependent windows of ~1100 cycles) and 2 us per member once the chip's issue slots are full (10^5 reads:
+// 13.8 ms), so the first piece's kernel should end when the second piece's copy does; kernels of several streams did not
+// overlap (measured: 18 pieces of 16 MB on four streams 46 ms after the copies, 4 pieces on one stream 26 ms).
+extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t file_bytes)
+{
+    if (!ctx || (file_bytes && !file)) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_stage_file: NULL argument");
+    MSQ_HIP(hipSetDevice(ctx->device));
+    msq_bgzf_drop_staged(ctx);
+    if (file_bytes == 0) return MSQ_OK;  // nothing to stage: forgets an image staged before (a caller that gave up on its file)
+    const uint64_t file_padded = ((file_bytes + 3) & ~3ull) + 1024;  // the bit reader looks two chunks ahead
+    void* scratch = nullptr;
+    if (int rc = msq_scratch(ctx, file_padded + 256, &scratch)) return rc;
+    MSQ_HIP(hipStreamSynchronize(ctx->stream));  // the scratch's previous user is done
+    if (!ctx->copy_stream) MSQ_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    char* const d_file = (char*)scratch;
+    MSQ_HIP(hipMemsetAsync(d_file + (file_bytes & ~3ull), 0, file_padded - (file_bytes & ~3ull), ctx->copy_stream));
+    MSQ_HIP(hipStreamSynchronize(ctx->copy_stream));  // before the last piece's copy writes the bytes beside the padding
+    const int n_pieces = file_bytes >= ctx->bam_piece_min_bytes ? (int)std::min<uint64_t>(8, std::max<uint64_t>(1, ctx->bam_pieces)) : 1;
+    for (int k = 0; k < n_pieces; ++k) {
+        ctx->staged_upto[k] = k + 1 == n_pieces ? file_bytes
+                              : n_pieces == 2   ? file_bytes / 100 * ctx->bam_first_share_pct
+                                                : file_bytes / (uint64_t)(n_pieces + 1) * (uint64_t)(k + 1);
+        ctx->staged_event[k] = nullptr;
+        hipError_t e = hipEventCreateWithFlags(&ctx->staged_event[k], hipEventDisableTiming);
+        ctx->staged_total = k + 1;
+        if (e != hipSuccess) {
+            msq_bgzf_drop_staged(ctx);
+            return msq_fail(MSQ_ERR_HIP, "msq_bgzf_stage_file: %s", hipGetErrorString(e));
+        }
+    }
+    ctx->staged_file = file;
+    ctx->staged_bytes = file_bytes;
+    ctx->stage_thread = new (std::nothrow) std::thread([ctx, file, d_file, n_pieces] {
+        hipError_t e = hipSetDevice(ctx->device);
+        uint64_t copied = 0;
+        for (int k = 0; k < n_pieces; ++k) {
+            const uint64_t upto = ctx->staged_upto[k];
+            if (e == hipSuccess && upto > copied) e = hipMemcpyAsync(d_file + copied, file + copied, upto - copied, hipMemcpyHostToDevice, ctx->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(ctx->staged_event[k], ctx->copy_stream);
+            if (e != hipSuccess) {
+                ctx->staged_err.store((int)e);
+                ctx->staged_done.store(n_pieces, std::memory_order_release);  // nobody waits for a piece that will not come
+                return;
+            }
+            copied = upto;
+            ctx->staged_done.store(k + 1, std::memory_order_release);
+        }
+    });
+    if (!ctx->stage_thread) {
+        msq_bgzf_drop_staged(ctx);
+        return msq_fail(MSQ_ERR_NOMEM, "msq_bgzf_stage_file: cannot start the copy thread");
+    }
+    return MSQ_OK;
+}
+
 extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64_t file_bytes, const msq_bgzf_member* members,
                                        uint64_t n_members, msq_bam_dev** out)
 {
@@ -468,6 +557,7 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
     if ((file_bytes && !file) || (n_members && !members)) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_inflate_device: NULL array");
     if (n_members > 0xfffffff0ull) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_inflate_device: too many members");
     uint64_t total = 0;
+    bool ordered = true;  // members in file order (a BGZF file's are): a piece's members are a range
     for (uint64_t m = 0; m < n_members; ++m) {
         const msq_bgzf_member& k = members[m];
         if (k.in_off > file_bytes || k.in_len > file_bytes - k.in_off) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_inflate_device: member %llu lies outside the file", (unsigned long long)m);
@@ -475,90 +565,75 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
         if (k.out_len > 65536u) return msq_fail(MSQ_ERR_DATA, "BGZF block %llu claims %u bytes (more than 64 KiB)", (unsigned long long)m, k.out_len);
         if (k.out_off != total) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_inflate_device: member %llu does not follow its predecessor in the output", (unsigned long long)m);
         total += k.out_len;
+        if (m && (k.in_off < members[m - 1].in_off || k.in_off + k.in_len < members[m - 1].in_off + members[m - 1].in_len)) ordered = false;
     }
     MSQ_HIP(hipSetDevice(ctx->device));
     const bool trace = getenv("MSQ_BAM_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [&t0]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const bool was_staged = ctx->staged_total > 0 && ctx->staged_file == file && ctx->staged_bytes == file_bytes;
+    if (!was_staged)
+        if (int rc = msq_bgzf_stage_file(ctx, file, file_bytes)) return rc;
+    if (!ctx->copy_stream) MSQ_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    const double t_staged = ms_since();
     msq_bam_dev* b = new (std::nothrow) msq_bam_dev;
-    if (!b) return msq_fail(MSQ_ERR_NOMEM, "msq_bgzf_inflate_device: out of memory");
-    // the file image, the member table and the status words live in the context's scratch (no allocation per call once it
-    // has grown); the inflated stream is the caller's to keep
-    const uint64_t file_padded = ((file_bytes + 3) & ~3ull) + 1024;  // the bit reader looks two chunks ahead
-    const uint64_t table_bytes = (std::max<uint64_t>(n_members, 1) * sizeof(msq_bgzf_member) + 255) & ~255ull;
-    const uint64_t status_bytes = (std::max<uint64_t>(n_members, 1) * 4 + 255) & ~255ull;
-    void* scratch = nullptr;
-    if (int rc = msq_scratch(ctx, file_padded + 256 + table_bytes + status_bytes, &scratch)) {
-        delete b;
-        return rc;
+    if (!b) {
+        msq_bgzf_drop_staged(ctx);
+        return msq_fail(MSQ_ERR_NOMEM, "msq_bgzf_inflate_device: out of memory");
     }
-    char* const d_file = (char*)scratch;
-    char* const d_members = d_file + ((file_padded + 255) & ~255ull);
-    char* const d_status = d_members + table_bytes;
     auto fail = [&](int code, const char* what, hipError_t e) {
         (void)hipStreamSynchronize(ctx->stream);
-        if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+        msq_bgzf_drop_staged(ctx);
         free_bam_dev(b);
         return msq_fail(code, "msq_bgzf_inflate_device: %s: %s", what, hipGetErrorString(e));
     };
-    hipError_t e = hipMalloc((void**)&b->d_data, total + MSQ_BAM_DATA_PAD);
+    // the file image sits in the context's scratch (msq_bgzf_stage_file); the member table and the status words in a
+    // buffer of the context's own that grows on demand; the inflated stream is the caller's to keep
+    const uint64_t file_padded = ((file_bytes + 3) & ~3ull) + 1024;
+    const uint64_t table_bytes = (std::max<uint64_t>(n_members, 1) * sizeof(msq_bgzf_member) + 255) & ~255ull;
+    const uint64_t status_bytes = (std::max<uint64_t>(n_members, 1) * 4 + 255) & ~255ull;
+    hipError_t e = hipSuccess;
+    if (ctx->bam_tables_bytes < table_bytes + status_bytes) {
+        if (ctx->d_bam_tables) (void)hipFree(ctx->d_bam_tables);
+        ctx->d_bam_tables = nullptr;
+        ctx->bam_tables_bytes = 0;
+        const size_t want = (size_t)(table_bytes + status_bytes) * 2;
+        e = hipMalloc(&ctx->d_bam_tables, want);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "hipMalloc", e);
+        ctx->bam_tables_bytes = want;
+    }
+    char* const d_file = (char*)ctx->d_scratch;
+    char* const d_members = (char*)ctx->d_bam_tables;
+    char* const d_status = d_members + table_bytes;
+    e = hipMalloc((void**)&b->d_data, total + MSQ_BAM_DATA_PAD);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "hipMalloc", e);
     b->data_bytes = total;
-    const double t_alloc = ms_since();
-    if (!ctx->copy_stream) {
-        e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
-        if (e != hipSuccess) return fail(MSQ_ERR_HIP, "hipStreamCreate", e);
-    }
     std::vector<uint32_t> status;
     try {
         status.resize(n_members);
     } catch (const std::bad_alloc&) {
         return fail(MSQ_ERR_NOMEM, "status", hipErrorOutOfMemory);
     }
-    e = hipMemsetAsync(d_file + (file_bytes & ~3ull), 0, file_padded - (file_bytes & ~3ull), ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(b->d_data + total, 0, MSQ_BAM_DATA_PAD, ctx->stream);
+    e = hipMemsetAsync(b->d_data + total, 0, MSQ_BAM_DATA_PAD, ctx->stream);
     if (e == hipSuccess && n_members) e = hipMemcpyAsync(d_members, members, n_members * sizeof(msq_bgzf_member), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0xFF, status_bytes, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the scratch's previous user is done, the padding is written
-    if (e != hipSuccess) return fail(MSQ_ERR_HIP, "upload", e);
-    // The file crosses PCIe in pieces on a stream of its own while the members of the pieces before are inflated: the
-    // copy of a pageable mapping keeps this thread busy, the kernels run beside it.  Two pieces only: a kernel takes ~6 ms
-    // however few members it has (one member is one wave, ~14 000 dependent windows of ~1100 cycles), 2.3 us per member
-    // once the chip's issue slots are full (10^5 reads: 16 ms), and the kernels of several streams did not overlap
-    // (measured: 18 pieces of 16 MB on four streams 46 ms after the copies, 4 pieces on one stream 26 ms).
-    // (A wave may look up to two chunks past its member into bytes that have not arrived: bits no valid stream consumes.)
-    std::vector<hipEvent_t> arrived;
-    auto drop_events = [&]() {
-        for (hipEvent_t ev : arrived) (void)hipEventDestroy(ev);
-        arrived.clear();
-    };
-    bool ordered = true;  // members in file order (a BGZF file's are): pieces are member ranges
-    for (uint64_t m = 1; m < n_members; ++m) ordered = ordered && members[m].in_off >= members[m - 1].in_off;
-    const uint64_t n_pieces = (ordered && file_bytes >= ctx->bam_piece_min_bytes) ? std::max<uint64_t>(1, ctx->bam_pieces) : 1;
-    uint64_t copied = 0;  // file bytes on their way
-    for (uint64_t m0 = 0, piece = 0; e == hipSuccess && m0 < n_members; ++piece) {
-        uint64_t m1 = m0 + 1, upto = file_bytes;
-        if (piece + 1 < n_pieces) {  // up to the member that crosses this piece's share of the file
-            // the last piece is twice the size of the others: its kernel has no copy to wait for, and a kernel costs ~6 ms
-            // however small its piece (first_share_pct: experiments)
-            const uint64_t share = n_pieces == 2 ? file_bytes / 100 * ctx->bam_first_share_pct : file_bytes / (n_pieces + 1) * (piece + 1);
-            while (m1 < n_members && members[m1 - 1].in_off + members[m1 - 1].in_len < share) ++m1;
-            upto = members[m1 - 1].in_off + members[m1 - 1].in_len;
-        } else {
-            m1 = n_members;
+    // every piece's members behind its copy.  (A wave may look up to two chunks past its member into bytes that have not
+    // arrived: bits no valid stream consumes.)
+    uint64_t m0 = 0;
+    for (int k = 0; e == hipSuccess && k < ctx->staged_total; ++k) {
+        const bool last = k + 1 == ctx->staged_total;
+        uint64_t m1 = m0;
+        if (last || !ordered)
+            m1 = last ? n_members : m0;
+        else
+            while (m1 < n_members && members[m1].in_off + members[m1].in_len <= ctx->staged_upto[k]) ++m1;
+        while (ctx->staged_done.load(std::memory_order_acquire) <= k) usleep(20);  // the copy thread has recorded this piece's event
+        if (ctx->staged_err.load()) {
+            e = (hipError_t)ctx->staged_err.load();
+            break;
         }
-        if (upto > copied) {
-            e = hipMemcpyAsync(d_file + copied, file + copied, upto - copied, hipMemcpyHostToDevice, ctx->copy_stream);
-            copied = upto;
-            hipEvent_t ev = nullptr;
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (e == hipSuccess) {
-                arrived.push_back(ev);
-                e = hipEventRecord(ev, ctx->copy_stream);
-            }
-            if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ev, 0);
-        }
-        if (e == hipSuccess) {
+        e = hipStreamWaitEvent(ctx->stream, ctx->staged_event[k], 0);
+        if (e == hipSuccess && m1 > m0) {
             hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((m1 - m0 + 3) / 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_file, file_padded / 4,
                                (const msq_bgzf_member*)d_members + m0, (uint32_t)(m1 - m0), b->d_data, (uint32_t*)d_status + m0);
             e = hipGetLastError();
@@ -568,15 +643,11 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
     const double t_issued = ms_since();
     if (e == hipSuccess && n_members) e = hipMemcpyAsync(status.data(), d_status, n_members * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-        (void)hipStreamSynchronize(ctx->copy_stream);
-        drop_events();
-        return fail(MSQ_ERR_HIP, "inflate kernel", e);
-    }
-    drop_events();
+    if (e != hipSuccess) return fail(MSQ_ERR_HIP, "inflate kernel", e);
+    msq_bgzf_drop_staged(ctx);
     if (trace)
-        std::fprintf(stderr, "msq_bgzf_inflate_device: %llu members, %.1f MB -> %.1f MB: alloc %.2f ms, copies + launches issued at %.2f ms, done at %.2f ms\n",
-                     (unsigned long long)n_members, file_bytes / 1e6, total / 1e6, t_alloc, t_issued, ms_since());
+        std::fprintf(stderr, "msq_bgzf_inflate_device: %llu members, %.1f MB -> %.1f MB: %s at %.2f ms, launches issued at %.2f ms, done at %.2f ms\n",
+                     (unsigned long long)n_members, file_bytes / 1e6, total / 1e6, was_staged ? "image staged by the caller, taken" : "image staged", t_staged, t_issued, ms_since());
     for (uint64_t m = 0; m < n_members; ++m)
         if (status[m] != INF_OK) {
             free_bam_dev(b);

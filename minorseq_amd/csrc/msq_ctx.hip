@@ -123,6 +123,8 @@ extern "C" int msq_ctx_destroy(msq_ctx* ctx)
         if (ctx->h_stage[k]) (void)hipHostFree(ctx->h_stage[k]);
         if (ctx->stage_done[k]) (void)hipEventDestroy(ctx->stage_done[k]);
     }
+    msq_bgzf_drop_staged(ctx);
+    if (ctx->d_bam_tables) (void)hipFree(ctx->d_bam_tables);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     timing_release(ctx);
     delete ctx;

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/msq_abi.h"
@@ -61,9 +63,18 @@ struct msq_ctx {
     bool no_haps = false;              // MSQ_NO_HAPS / MSQ_TUNE_NO_HAPS: msq_reads_align makes no haplotype groups
     // msq_bgzf_inflate_device: the file image's pieces cross PCIe on copy_stream beside the inflate kernels of the pieces before
     hipStream_t copy_stream = nullptr;
+    // msq_bgzf_stage_file: the file image now in the scratch (host pointer and size as its name), the pieces' ends and events
+    const uint8_t* staged_file = nullptr;
+    uint64_t staged_bytes = 0, staged_upto[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t staged_event[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int staged_total = 0;                // pieces of the staged image; staged_done of them have their event recorded
+    std::atomic<int> staged_done{0}, staged_err{0};
+    std::thread* stage_thread = nullptr; // issues the copies (a pageable copy blocks its thread)
+    void* d_bam_tables = nullptr;        // msq_bgzf_inflate_device: member table + status words
+    size_t bam_tables_bytes = 0;
     uint64_t bam_pieces = 2;             // msq_bgzf_inflate_device: pieces a file of >= bam_piece_min_bytes is uploaded and inflated in
     uint64_t bam_piece_min_bytes = (uint64_t)32 << 20;
-    uint64_t bam_first_share_pct = 33;   // two pieces: the first one's share of the file
+    uint64_t bam_first_share_pct = 40;   // two pieces: the first one's share of the file
     uint64_t bam_segment_bytes = 16384;  // msq_bam_index_device: the stream is searched for record starts in segments of this size
 };
 
@@ -95,6 +106,7 @@ int msq_fail(int code, const char* fmt, ...);
     } while (0)
 
 int msq_scratch(msq_ctx* ctx, size_t bytes, void** out);
+void msq_bgzf_drop_staged(msq_ctx* ctx);  // msq_bgzf.hip: forget a staged file image (joins its copy thread)
 int msq_noalloc_init(msq_ctx* ctx);
 // allocate and build the group column index of a library-owned device set (ptrs[8], view.gcol); async
 int msq_packed_dev_index(msq_ctx* ctx, msq_packed_dev* d);
