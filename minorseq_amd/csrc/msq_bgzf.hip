@@ -51,13 +51,40 @@ enum : uint32_t {
 };
 
 constexpr int LIT_BITS = 10, DIST_BITS = 9, CL_BITS = 7;
-// a primary-table entry is (symbol << 4 | code length), with bit 15 set on everything that is not a literal: one compare
-// keeps the literal loop going
+// A primary-table entry is (payload << 4 | code length); code length 0: a longer code, or none.  Bit 15 is set on
+// everything the fast path does not take as it is (one compare keeps the literal loop going):
+//   code-length alphabet   payload = symbol
+//   literal/length         a literal: payload = the byte.  Anything else: bit 15, and payload = (base - 3) << 3 | extra
+//                          bits for a length code (RFC 1951 3.2.5: bases 3..258, 0..5 extra bits), 6 for the end-of-block
+//                          code, 7 for symbols 286 / 287 -- the match path has no arithmetic on symbol numbers left
+//   distance               payload = top << 4 | extra bits, distance = (top << extra) + 1 + the extra bits' value (top =
+//                          the symbol below 4, else 2 + its low bit; extra = symbol / 2 - 1); symbols 30 / 31: bit 15
 constexpr uint32_t kNotLiteral = 0x8000u;
+enum { CODE_PLAIN = 0, CODE_LITLEN = 1, CODE_DIST = 2 };
+constexpr uint32_t kLenEob = 6, kLenInvalid = 7;
+
+__device__ inline uint32_t litlen_payload(uint32_t sym)  // of a symbol >= 256
+{
+    if (sym == 256) return kLenEob;
+    if (sym > 285) return kLenInvalid;
+    if (sym < 265) return (sym - 257u) << 3;
+    if (sym == 285) return 255u << 3;
+    const uint32_t xb = (sym - 261u) >> 2;
+    return (((4u + ((sym - 265u) & 3u)) << xb) << 3) | xb;
+}
+__device__ inline uint32_t dist_payload(uint32_t sym)  // of a symbol <= 29
+{
+    if (sym < 4) return sym << 4;
+    return ((2u + (sym & 1u)) << 4) | ((sym >> 1) - 1u);
+}
 
 struct CodeSet {  // a canonical Huffman code, per code length 1..15: first code, number of codes, offset into `sorted`
     uint16_t first[16], count[16], offs[16];
 };
+
+#ifndef INF_FENCE_SCOPE
+#define INF_FENCE_SCOPE "workgroup"
+#endif
 
 struct WaveLds {
     uint16_t lit[1 << LIT_BITS];    // (symbol << 4 | length | kNotLiteral) by the next LIT_BITS bits; length 0: a longer code, or none
@@ -92,9 +119,18 @@ struct BitReader {
     uint32_t cur, nxt;      // lane i: dword (widx & ~63) + i, and the one 64 dwords on
     int lane;
 
-    // clamped, not predicated: the last dwords of the image are zero padding, and a load that always happens can land
-    // in the register that carries it to its use 64 refills later (no wait where it is issued)
-    __device__ uint32_t load(uint64_t w) const { return words[w < nwords ? w : nwords - 1]; }
+    // Clamped, not predicated (the last dwords of the image are zero padding), and hand-written with its wait inside: a
+    // load the compiler tracks stays "pending" in its view of cur / nxt around the symbol loop, and every copy it makes of
+    // the two registers (one per match) then gets an s_waitcnt vmcnt(0) -- which also waits for the acknowledgement of
+    // every store the wave has in flight, two memory round trips per match.  Waiting here costs one round trip per 64
+    // dwords of input.
+    __device__ uint32_t load(uint64_t w) const
+    {
+        const uint32_t* p = words + (w < nwords ? w : nwords - 1);
+        uint32_t v;
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
     __device__ void refill()  // afterwards cnt > 32
     {
         if (cnt <= 32) {
@@ -140,7 +176,7 @@ struct BitReader {
 // Canonical code of n symbols with code lengths lens[] (0 = unused): per-length tables, symbols in canonical order and
 // the primary lookup table over the next TBITS bits.  zlib's rules (inflate_table): an over-subscribed set is an
 // error, an incomplete one too unless it has no code longer than one bit and the alphabet may be incomplete.
-template <int TBITS>
+template <int TBITS, int KIND>
 __device__ __noinline__ uint32_t build_code(const uint8_t* lens, int n, uint16_t* table, uint16_t* sorted, CodeSet* cs, uint32_t* cnt,
                                bool may_be_incomplete, int lane)
 {
@@ -205,7 +241,12 @@ __device__ __noinline__ uint32_t build_code(const uint8_t* lens, int n, uint16_t
             const uint32_t d = (__brev(e) >> (32 - L)) - f;  // the entry's first L bits as a code (first bit = MSB)
             if (d < c) {
                 const uint32_t sym = sorted[o + d];
-                ent[k] = (uint32_t)L | (sym << 4) | (sym >= 256 ? kNotLiteral : 0u);
+                if (KIND == CODE_LITLEN)
+                    ent[k] = (uint32_t)L | (sym < 256 ? sym << 4 : kNotLiteral | (litlen_payload(sym) << 4));
+                else if (KIND == CODE_DIST)
+                    ent[k] = (uint32_t)L | (sym <= 29 ? dist_payload(sym) << 4 : kNotLiteral);
+                else
+                    ent[k] = (uint32_t)L | (sym << 4);
             }
         }
     }
@@ -240,12 +281,26 @@ __device__ inline uint32_t decode_sym(uint64_t buf, const uint16_t* table, const
 }
 
 // A member that cannot be inflated ends its wave on the spot (status word, s_endpgm): with plain returns out of the nested
-// loops the compiler threads an exit code through every loop level, and the kernel is bound by instruction issue.
-#define INF_FAIL(code)                       \
-    do {                                     \
-        if (lane == 0) *status = (code);     \
-        __builtin_amdgcn_endpgm();           \
-    } while (0)
+// loops the compiler threads an exit code through every loop level, and the kernel is bound by instruction issue.  One
+// asm statement that, as far as the compiler knows, comes back: a failing branch is then a plain uniform if-then.  (As
+// `if (lane == 0) *status = code; __builtin_amdgcn_endpgm();`, or declared noreturn, every failing branch is an exit
+// of the symbol loop, the compiler joins all exits of a function into one block, and the paths to it run through flag
+// registers that the good path has to set -- a dozen scalar moves per match.)
+__device__ inline void inflate_fail(uint32_t* status, uint32_t code, int lane)
+{
+    uint32_t z, c;
+    asm volatile(
+        "v_mov_b32 %[z], 0\n\t"
+        "v_mov_b32 %[c], %[code]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[lane]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "global_store_dword %[z], %[c], %[st]\n\t"
+        "s_endpgm"
+        : [z] "=&v"(z), [c] "=&v"(c)
+        : [code] "s"(code), [lane] "v"(lane), [st] "s"(status)
+        : "vcc", "memory");
+}
+#define INF_FAIL(code) inflate_fail(status, (code), lane)
 
 __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t file_words, const msq_bgzf_member mem,
                                    uint8_t* __restrict__ out, WaveLds& S, int lane, uint32_t* __restrict__ status)
@@ -262,7 +317,6 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
     br.init(mem.in_off);
     uint32_t pos = 0;  // bytes written
     bool fixed_ready = false;
-    const uint64_t below = (1ull << lane) - 1ull;
     for (;;) {
         if (br.bit_pos() + 3 > end_bit) INF_FAIL(INF_ERR_INPUT);
         br.refill();
@@ -302,7 +356,7 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     if (lane == 0) S.cl_lens[kClOrder[i]] = (uint8_t)v;
                 }
                 WAVE_SYNC();
-                if (const uint32_t e = uni(build_code<CL_BITS>(S.cl_lens, 19, S.cl, S.sorted_cl, &S.cs_cl, S.cnt, false, lane))) INF_FAIL(e);
+                if (const uint32_t e = uni(build_code<CL_BITS, CODE_PLAIN>(S.cl_lens, 19, S.cl, S.sorted_cl, &S.cs_cl, S.cnt, false, lane))) INF_FAIL(e);
                 const int total = n_lit + n_dist;
                 int i = 0;
                 uint32_t prev = 0;
@@ -340,8 +394,8 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 if (uni(S.lens[256]) == 0) INF_FAIL(INF_ERR_NOEOB);
             }
             if (btype == 2 || !fixed_ready) {
-                if (const uint32_t e = uni(build_code<LIT_BITS>(S.lens, n_lit, S.lit, S.sorted_lit, &S.cs_lit, S.cnt, true, lane))) INF_FAIL(e);
-                if (const uint32_t e = uni(build_code<DIST_BITS>(S.lens + n_lit, n_dist, S.dist, S.sorted_dist, &S.cs_dist, S.cnt, true, lane))) INF_FAIL(e);
+                if (const uint32_t e = uni(build_code<LIT_BITS, CODE_LITLEN>(S.lens, n_lit, S.lit, S.sorted_lit, &S.cs_lit, S.cnt, true, lane))) INF_FAIL(e);
+                if (const uint32_t e = uni(build_code<DIST_BITS, CODE_DIST>(S.lens + n_lit, n_dist, S.dist, S.sorted_dist, &S.cs_dist, S.cnt, true, lane))) INF_FAIL(e);
                 fixed_ready = btype == 1;
             }
             for (;;) {
@@ -356,14 +410,18 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     // where the chain goes on from offset `lane`: behind the literal that starts there, or to 64 when the code
                     // there is no literal (or no code of the primary table)
                     const uint32_t onward = (mine & kNotLiteral) ? 64u : (uint32_t)lane + (mine & 15u);
-                    // the chain walk, five scalar instructions per literal (hand-written: the compiler's version of this loop
-                    // took thirteen, and the kernel is bound by instruction issue): every offset visited gets its bit in
-                    // `starts`; the walk ends behind the window (k <= 59) or at a non-literal (k = 64, its offset the last bit
-                    // set).  The lane select of v_readlane is written by s_mov, never directly by the v_readlane before it
-                    // (a VALU-written SGPR as lane select needs wait states).
-                    uint64_t starts;
+                    // The rest of the window is hand-written (the kernel is bound by the issue of scalar instructions, and
+                    // the compiler's version of this part took about twice as many).  The chain walk, five instructions per
+                    // literal: every offset visited gets its bit in `starts`; the walk ends behind the window (k <= 59) or
+                    // at a non-literal (k = 64, its offset the last bit set, which is then taken out again and its entry
+                    // read into e).  The lane select of v_readlane is written by s_mov, never directly by the v_readlane
+                    // before it (a VALU-written SGPR as lane select needs wait states).  Then the literals leave in one
+                    // store: exec = starts, a lane's rank among the starts is v_mbcnt of exec, and a byte at or beyond
+                    // out_len is not written (pos runs on and the member fails at its next match or at its end, as it
+                    // does in zlib); last the bits walked over are dropped.
+                    uint64_t starts, save;
                     int k;
-                    uint32_t tmp;
+                    uint32_t tmp, vaddr, vdata;
                     asm volatile(
                         "s_mov_b64 %[st], 0\n\t"
                         "s_mov_b32 %[k], 0\n"
@@ -372,71 +430,90 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                         "v_readlane_b32 %[t], %[onward], %[k]\n\t"
                         "s_mov_b32 %[k], %[t]\n\t"
                         "s_cmp_le_i32 %[k], %[K]\n\t"
-                        "s_cbranch_scc1 1b"
-                        : [st] "=&s"(starts), [k] "=&s"(k), [t] "=&s"(tmp)
-                        : [onward] "v"(onward), [K] "s"(K)
-                        : "scc");
-                    const bool more = k < 64;
-                    if (!more) {  // the last offset visited holds the non-literal: it is no start of a literal
-                        k = 63 - __builtin_clzll(starts);
-                        starts &= ~(1ull << k);
-                        e = (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
-                    }
-                    if (starts) {
-                        const uint32_t n = (uint32_t)__popcll(starts);
-                        if (pos + n > out_len) INF_FAIL(INF_ERR_OUTPUT);
-                        if ((starts >> lane) & 1ull) dst[pos + (uint32_t)__popcll(starts & below)] = (uint8_t)(mine >> 4);
-                        pos += n;
-                    }
-                    br.drop(k);
-                    if (!more) break;
+                        "s_cbranch_scc1 1b\n\t"
+                        "s_mov_b32 %[e], 0\n\t"
+                        "s_cmp_lt_i32 %[k], 64\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "s_flbit_i32_b64 %[t], %[st]\n\t"
+                        "s_xor_b32 %[k], %[t], 63\n\t"
+                        "s_bitset0_b64 %[st], %[k]\n\t"
+                        "v_readlane_b32 %[e], %[mine], %[k]\n"
+                        "2:\n\t"
+                        "s_bcnt1_i32_b64 %[t], %[st]\n\t"
+                        "s_mov_b64 %[save], exec\n\t"
+                        "s_mov_b64 exec, %[st]\n\t"
+                        "v_mbcnt_lo_u32_b32 %[va], exec_lo, 0\n\t"
+                        "v_mbcnt_hi_u32_b32 %[va], exec_hi, %[va]\n\t"
+                        "v_add_u32_e32 %[va], %[pos], %[va]\n\t"
+                        "v_lshrrev_b32_e32 %[vd], 4, %[mine]\n\t"
+                        "v_cmp_gt_u32_e32 vcc, %[outlen], %[va]\n\t"
+                        "s_and_b64 exec, exec, vcc\n\t"
+                        "global_store_byte %[va], %[vd], %[dst]\n\t"
+                        "s_mov_b64 exec, %[save]\n\t"
+                        "s_add_u32 %[pos], %[pos], %[t]\n\t"
+                        "s_lshr_b64 %[buf], %[buf], %[k]\n\t"
+                        "s_sub_u32 %[cnt], %[cnt], %[k]"
+                        : [st] "=&s"(starts), [k] "=&s"(k), [t] "=&s"(tmp), [e] "=&s"(e), [save] "=&s"(save), [va] "=&v"(vaddr),
+                          [vd] "=&v"(vdata), [pos] "+s"(pos), [buf] "+s"(br.buf), [cnt] "+s"(br.cnt)
+                        : [onward] "v"(onward), [mine] "v"(mine), [K] "s"(K), [outlen] "s"(out_len), [dst] "s"(dst)
+                        : "scc", "vcc", "memory");
+                    if (e) break;
                 }
                 br.refill();  // the window may have left as few as 15 bits: the code below and its extra bits take up to 20
-                e &= ~kNotLiteral;
-                if ((e & 15u) == 0) {
-                    e = uni(long_sym<LIT_BITS>((uint32_t)br.buf, S.sorted_lit, &S.cs_lit));
-                    if (!e) INF_FAIL(INF_ERR_SYMBOL);
+                uint32_t cl = e & 15u;
+                if (cl == 0) {  // a code longer than the primary table's bits (or no code at all)
+                    const uint32_t raw = uni(long_sym<LIT_BITS>((uint32_t)br.buf, S.sorted_lit, &S.cs_lit));
+                    if (!raw) INF_FAIL(INF_ERR_SYMBOL);
+                    cl = raw & 15u;
+                    const uint32_t sym = raw >> 4;
+                    if (sym < 256) {  // a literal with a long code
+                        br.drop((int)cl);
+                        if (pos >= out_len) INF_FAIL(INF_ERR_OUTPUT);
+                        dst[pos] = (uint8_t)sym;  // every lane, the same byte: no divergent branch (see below)
+                        ++pos;
+                        continue;
+                    }
+                    e = litlen_payload(sym) << 4;
                 }
-                br.drop((int)(e & 15u));
-                const uint32_t sym = e >> 4;
-                if (sym < 256) {  // a literal with a long code
-                    if (pos >= out_len) INF_FAIL(INF_ERR_OUTPUT);
-                    if (lane == 0) dst[pos] = (uint8_t)sym;
-                    ++pos;
-                    continue;
+                br.drop((int)cl);
+                const int xb = (int)((e >> 4) & 7u);
+                if (xb >= (int)kLenEob) {
+                    if (xb == (int)kLenInvalid) INF_FAIL(INF_ERR_SYMBOL);
+                    break;  // end of block
                 }
-                if (sym == 256) break;
-                if (sym > 285) INF_FAIL(INF_ERR_SYMBOL);
-                uint32_t len;
-                if (sym < 265) {
-                    len = sym - 254;
-                } else if (sym == 285) {
-                    len = 258;
-                } else {
-                    const int xb = (int)((sym - 261) >> 2);
-                    len = ((4u + ((sym - 265) & 3u)) << xb) + 3u + br.bits(xb);
-                }
+                const uint32_t len = ((e >> 7) & 0xffu) + 3u + br.bits(xb);
                 br.refill();
-                const uint32_t de = decode_sym<DIST_BITS>(br.buf, S.dist, S.sorted_dist, &S.cs_dist);
-                if (!de) INF_FAIL(INF_ERR_SYMBOL);
-                br.drop((int)(de & 15u));
-                const uint32_t dsym = de >> 4;
-                if (dsym > 29) INF_FAIL(INF_ERR_DIST);
-                uint32_t dist;
-                if (dsym < 4) {
-                    dist = dsym + 1;
-                } else {
-                    const int xb = (int)(dsym >> 1) - 1;
-                    dist = ((2u + (dsym & 1u)) << xb) + 1u + br.bits(xb);
+                uint32_t d = uni(S.dist[(uint32_t)br.buf & ((1u << DIST_BITS) - 1u)]);
+                uint32_t dcl = d & 15u;
+                if (d & kNotLiteral) {
+                    if (dcl) INF_FAIL(INF_ERR_DIST);  // symbols 30 / 31
+                    const uint32_t raw = uni(long_sym<DIST_BITS>((uint32_t)br.buf, S.sorted_dist, &S.cs_dist));
+                    if (!raw) INF_FAIL(INF_ERR_SYMBOL);
+                    if ((raw >> 4) > 29) INF_FAIL(INF_ERR_DIST);
+                    dcl = raw & 15u;
+                    d = dist_payload(raw >> 4) << 4;
                 }
+                br.drop((int)dcl);
+                const int dxb = (int)((d >> 4) & 15u);
+                const uint32_t dist = (((d >> 8) & 3u) << dxb) + 1u + br.bits(dxb);
                 if (dist > pos) INF_FAIL(INF_ERR_DIST);
                 if (pos + len > out_len) INF_FAIL(INF_ERR_OUTPUT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the copy reads what this wave has stored
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, INF_FENCE_SCOPE);  // the copy reads what this wave has stored
                 const uint8_t* src = dst + (pos - dist);
+                // A uniform loop of copies without a branch on the lane (most matches take one pass): the lanes beyond the
+                // match repeat its last byte.  With any divergent branch in the symbol loop the compiler structurizes
+                // the whole loop and joins its paths through flag registers, a dozen scalar moves per match.
+                const uint32_t last = len - 1u;
                 if (dist >= len) {
-                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = src[i];
+                    for (uint32_t b0 = 0; b0 < len; b0 += 64) {
+                        const uint32_t i = min(b0 + (uint32_t)lane, last);
+                        dst[pos + i] = src[i];
+                    }
                 } else {  // the match overlaps itself: its bytes repeat with period dist, all of them already written
-                    for (uint32_t i = (uint32_t)lane; i < len; i += 64) dst[pos + i] = src[i % dist];
+                    for (uint32_t b0 = 0; b0 < len; b0 += 64) {
+                        const uint32_t i = min(b0 + (uint32_t)lane, last);
+                        dst[pos + i] = src[i % dist];
+                    }
                 }
                 pos += len;
             }
@@ -448,6 +525,9 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
     return INF_OK;
 }
 
+#ifdef INF_WAVES
+__attribute__((amdgpu_waves_per_eu(INF_WAVES, INF_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void bgzf_inflate_kernel(const uint32_t* __restrict__ file32, uint64_t file_words,
                                                            const msq_bgzf_member* __restrict__ members, uint32_t n_members,
                                                            uint8_t* __restrict__ out, uint32_t* __restrict__ status)
