@@ -507,7 +507,8 @@ typedef struct msq_bgzf_member {
     uint32_t out_len; /* ISIZE, <= 65536 */
 } msq_bgzf_member;
 typedef struct msq_bam_dev msq_bam_dev; /* a BAM file's inflated stream (and, after msq_bam_index_device, its record tables) in HBM */
-/* host arrays in (the file image may be a pageable mapping); synchronises.  zlib's inflate of every member, bit for bit. */
+/* host arrays in (the file image may be a pageable mapping); synchronises.  zlib's inflate of every member, bit for bit.
+ * A file image of 16 GiB or more is refused (MSQ_ERR_ARG: the kernel counts the image's dwords in 32 bits). */
 int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64_t file_bytes, const msq_bgzf_member* members,
                             uint64_t n_members, msq_bam_dev** out);
 /* Optional, ahead of msq_bgzf_inflate_device on the same (file, file_bytes): start the file image's way to the device

@@ -495,6 +495,8 @@ struct BamUtils
         {
             const MappedFile file(filePath);
             fileBytes = file.size();
+            // the device front takes a file image of less than 16 GiB at once (msq_bgzf_stage_file)
+            if (fileBytes >= (1ull << 34) - 4096) return BamToReadSource(filePath, regionStart, regionEnd, threads, timings, chemistries);
             // the file image starts on its way to the GPU (the library's copy thread) while this thread scans the BGZF
             // headers and reads the BAM header; whatever happens here, an image nobody will use is forgotten before the
             // mapping goes

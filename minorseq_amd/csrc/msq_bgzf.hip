@@ -113,7 +113,7 @@ __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_r
 struct BitReader {
     const uint32_t* words;  // the file image as dwords, zero-padded
     uint64_t nwords;
-    uint64_t widx;          // the next dword to take
+    uint32_t widx;          // the next dword to take (the host refuses images of 16 GiB and more)
     uint64_t buf;
     int cnt;                // valid bits in buf
     uint32_t cur, nxt;      // lane i: dword (widx & ~63) + i, and the one 64 dwords on
@@ -140,14 +140,14 @@ struct BitReader {
             ++widx;
             if ((widx & 63) == 0) {
                 cur = nxt;
-                nxt = load(widx + 64 + (uint64_t)lane);
+                nxt = load((uint64_t)widx + 64u + (uint64_t)lane);
             }
         }
     }
     __device__ void init(uint64_t byte_addr)
     {
-        widx = byte_addr >> 2;
-        const uint64_t cbase = widx & ~63ull;
+        widx = (uint32_t)(byte_addr >> 2);
+        const uint64_t cbase = (uint64_t)(widx & ~63u);
         cur = load(cbase + (uint64_t)lane);
         nxt = load(cbase + 64 + (uint64_t)lane);
         buf = 0;
@@ -170,7 +170,7 @@ struct BitReader {
         buf >>= n;
         cnt -= n;
     }
-    __device__ uint64_t bit_pos() const { return widx * 32 - (uint64_t)cnt; }  // of the next unread bit, from the file's start
+    __device__ uint64_t bit_pos() const { return (uint64_t)widx * 32 - (uint64_t)cnt; }  // of the next unread bit, from the file's start
 };
 
 // Canonical code of n symbols with code lengths lens[] (0 = unused): per-length tables, symbols in canonical order and
@@ -316,6 +316,8 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
     br.lane = lane;
     br.init(mem.in_off);
     uint32_t pos = 0;  // bytes written
+    bool pend = false;  // a match's bytes are loaded (pend_byte, lane by lane) and not yet stored (at pend_at)
+    uint32_t pend_at = 0, pend_byte = 0;
     bool fixed_ready = false;
     for (;;) {
         if (br.bit_pos() + 3 > end_bit) INF_FAIL(INF_ERR_INPUT);
@@ -405,41 +407,40 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     // chain of real code starts through those entries with v_readlane (no memory in the chain) and all
                     // literals of the window leave in one store.  One LDS access per ~5 literals instead of one each.
                     br.refill();
-                    const int K = br.cnt - 15;  // a code that starts at offset <= K has all its bits (and 5 to spare) in buf
+                    const uint32_t K1 = (uint32_t)br.cnt - 14u;  // a code that starts at an offset < K1 has all its bits (and 5 to spare) in buf
                     const uint32_t mine = S.lit[(uint32_t)(br.buf >> lane) & ((1u << LIT_BITS) - 1u)];
                     // where the chain goes on from offset `lane`: behind the literal that starts there, or to 64 when the code
                     // there is no literal (or no code of the primary table)
                     const uint32_t onward = (mine & kNotLiteral) ? 64u : (uint32_t)lane + (mine & 15u);
                     // The rest of the window is hand-written (the kernel is bound by the issue of scalar instructions, and
-                    // the compiler's version of this part took about twice as many).  The chain walk, five instructions per
-                    // literal: every offset visited gets its bit in `starts`; the walk ends behind the window (k <= 59) or
-                    // at a non-literal (k = 64, its offset the last bit set, which is then taken out again and its entry
-                    // read into e).  The lane select of v_readlane is written by s_mov, never directly by the v_readlane
-                    // before it (a VALU-written SGPR as lane select needs wait states).  Then the literals leave in one
+                    // the compiler's version of this part took about twice as many).  The chain walk, four instructions
+                    // per literal: every offset visited gets its bit in `starts`; s_min both copies the next offset into
+                    // the lane select (a VALU-written SGPR as lane select needs wait states, a SALU-written one none)
+                    // and compares it with the window's end (SCC = the first operand is the smaller one).  The walk
+                    // ends behind the window (next <= 64 - 5) or at a non-literal (next = 64, its offset the last bit
+                    // set, which is then taken out again and its entry read into e).  Then the literals leave in one
                     // store: exec = starts, a lane's rank among the starts is v_mbcnt of exec, and a byte at or beyond
                     // out_len is not written (pos runs on and the member fails at its next match or at its end, as it
                     // does in zlib); last the bits walked over are dropped.
                     uint64_t starts, save;
-                    int k;
-                    uint32_t tmp, vaddr, vdata;
+                    uint32_t k, next, vaddr, vdata;
                     asm volatile(
                         "s_mov_b64 %[st], 0\n\t"
                         "s_mov_b32 %[k], 0\n"
                         "1:\n\t"
                         "s_bitset1_b64 %[st], %[k]\n\t"
                         "v_readlane_b32 %[t], %[onward], %[k]\n\t"
-                        "s_mov_b32 %[k], %[t]\n\t"
-                        "s_cmp_le_i32 %[k], %[K]\n\t"
+                        "s_min_u32 %[k], %[t], %[K1]\n\t"
                         "s_cbranch_scc1 1b\n\t"
                         "s_mov_b32 %[e], 0\n\t"
-                        "s_cmp_lt_i32 %[k], 64\n\t"
+                        "s_cmp_lt_u32 %[t], 64\n\t"
                         "s_cbranch_scc1 2f\n\t"
                         "s_flbit_i32_b64 %[t], %[st]\n\t"
-                        "s_xor_b32 %[k], %[t], 63\n\t"
-                        "s_bitset0_b64 %[st], %[k]\n\t"
-                        "v_readlane_b32 %[e], %[mine], %[k]\n"
+                        "s_xor_b32 %[t], %[t], 63\n\t"
+                        "s_bitset0_b64 %[st], %[t]\n\t"
+                        "v_readlane_b32 %[e], %[mine], %[t]\n"
                         "2:\n\t"
-                        "s_bcnt1_i32_b64 %[t], %[st]\n\t"
+                        "s_bcnt1_i32_b64 %[k], %[st]\n\t"
                         "s_mov_b64 %[save], exec\n\t"
                         "s_mov_b64 exec, %[st]\n\t"
                         "v_mbcnt_lo_u32_b32 %[va], exec_lo, 0\n\t"
@@ -450,12 +451,12 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                         "s_and_b64 exec, exec, vcc\n\t"
                         "global_store_byte %[va], %[vd], %[dst]\n\t"
                         "s_mov_b64 exec, %[save]\n\t"
-                        "s_add_u32 %[pos], %[pos], %[t]\n\t"
-                        "s_lshr_b64 %[buf], %[buf], %[k]\n\t"
-                        "s_sub_u32 %[cnt], %[cnt], %[k]"
-                        : [st] "=&s"(starts), [k] "=&s"(k), [t] "=&s"(tmp), [e] "=&s"(e), [save] "=&s"(save), [va] "=&v"(vaddr),
+                        "s_add_u32 %[pos], %[pos], %[k]\n\t"
+                        "s_lshr_b64 %[buf], %[buf], %[t]\n\t"
+                        "s_sub_u32 %[cnt], %[cnt], %[t]"
+                        : [st] "=&s"(starts), [k] "=&s"(k), [t] "=&s"(next), [e] "=&s"(e), [save] "=&s"(save), [va] "=&v"(vaddr),
                           [vd] "=&v"(vdata), [pos] "+s"(pos), [buf] "+s"(br.buf), [cnt] "+s"(br.cnt)
-                        : [onward] "v"(onward), [mine] "v"(mine), [K] "s"(K), [outlen] "s"(out_len), [dst] "s"(dst)
+                        : [onward] "v"(onward), [mine] "v"(mine), [K1] "s"(K1), [outlen] "s"(out_len), [dst] "s"(dst)
                         : "scc", "vcc", "memory");
                     if (e) break;
                 }
@@ -498,18 +499,30 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 const uint32_t dist = (((d >> 8) & 3u) << dxb) + 1u + br.bits(dxb);
                 if (dist > pos) INF_FAIL(INF_ERR_DIST);
                 if (pos + len > out_len) INF_FAIL(INF_ERR_OUTPUT);
+                // The copy.  Alone in its SIMD a wave spends most of its time here, a memory round trip per match between
+                // the load of the source bytes and their store; so a match of up to 64 bytes (nearly all are) only loads,
+                // and its store waits until the next match (or the member's end) -- the window and the codes in between
+                // are decoded while the bytes are on their way.  The pending store goes out before the next load, whose
+                // source it may be: a wave's vector memory operations are performed in order.
+                if (pend) dst[pend_at] = (uint8_t)pend_byte;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, INF_FENCE_SCOPE);  // the copy reads what this wave has stored
                 const uint8_t* src = dst + (pos - dist);
-                // A uniform loop of copies without a branch on the lane (most matches take one pass): the lanes beyond the
-                // match repeat its last byte.  With any divergent branch in the symbol loop the compiler structurizes
-                // the whole loop and joins its paths through flag registers, a dozen scalar moves per match.
+                // No branch on the lane anywhere (the lanes beyond the match repeat its last byte): with any divergent
+                // branch in the symbol loop the compiler structurizes the whole loop and joins its paths through flag
+                // registers, a dozen scalar moves per match.
                 const uint32_t last = len - 1u;
-                if (dist >= len) {
+                pend = len <= 64;
+                if (pend) {
+                    uint32_t i = min((uint32_t)lane, last);
+                    pend_at = pos + i;
+                    if (dist < len) i %= dist;  // the match overlaps itself: its bytes repeat with period dist, all of them already written
+                    pend_byte = src[i];
+                } else if (dist >= len) {
                     for (uint32_t b0 = 0; b0 < len; b0 += 64) {
                         const uint32_t i = min(b0 + (uint32_t)lane, last);
                         dst[pos + i] = src[i];
                     }
-                } else {  // the match overlaps itself: its bytes repeat with period dist, all of them already written
+                } else {
                     for (uint32_t b0 = 0; b0 < len; b0 += 64) {
                         const uint32_t i = min(b0 + (uint32_t)lane, last);
                         dst[pos + i] = src[i % dist];
@@ -521,6 +534,7 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
         }
         if (bfinal) break;
     }
+    if (pend) dst[pend_at] = (uint8_t)pend_byte;
     if (pos != out_len) INF_FAIL(INF_ERR_SHORT);
     return INF_OK;
 }
@@ -552,6 +566,9 @@ static void free_bam_dev(msq_bam_dev* b)
 }
 
 // forget a staged image: its copy thread joined, its events destroyed (msq_ctx_destroy calls it too)
+static constexpr uint64_t kSlot = 8ull << 20;  // the upload ring (msq_bgzf_stage_file): pinned slots of 8 MB, eight of them
+static constexpr int kSlots = 8;
+
 void msq_bgzf_drop_staged(msq_ctx* ctx)
 {
     if (ctx->stage_thread) {
@@ -583,6 +600,7 @@ extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t f
     MSQ_HIP(hipSetDevice(ctx->device));
     msq_bgzf_drop_staged(ctx);
     if (file_bytes == 0) return MSQ_OK;  // nothing to stage: forgets an image staged before (a caller that gave up on its file)
+    if (file_bytes >= (1ull << 34) - 4096) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_stage_file: a file image of %llu bytes (the device front takes less than 16 GiB at once)", (unsigned long long)file_bytes);
     const uint64_t file_padded = ((file_bytes + 3) & ~3ull) + 1024;  // the bit reader looks two chunks ahead
     void* scratch = nullptr;
     if (int rc = msq_scratch(ctx, file_padded + 256, &scratch)) return rc;
@@ -592,10 +610,15 @@ extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t f
     MSQ_HIP(hipMemsetAsync(d_file + (file_bytes & ~3ull), 0, file_padded - (file_bytes & ~3ull), ctx->copy_stream));
     MSQ_HIP(hipStreamSynchronize(ctx->copy_stream));  // before the last piece's copy writes the bytes beside the padding
     const int n_pieces = file_bytes >= ctx->bam_piece_min_bytes ? (int)std::min<uint64_t>(8, std::max<uint64_t>(1, ctx->bam_pieces)) : 1;
+    // Pieces get smaller towards the end (two: the first share; more: sizes n + 1, n, ..., 2 in n (n + 3) / 2 parts): the
+    // members of a piece are inflated behind its copy, and what remains to do once the last byte has arrived is the last
+    // piece's kernel -- which, however few its members, takes as long as one wave needs for one member.
+    uint64_t parts = 0, parts_all = (uint64_t)n_pieces * (uint64_t)(n_pieces + 3) / 2;
     for (int k = 0; k < n_pieces; ++k) {
+        parts += (uint64_t)(n_pieces + 1 - k);
         ctx->staged_upto[k] = k + 1 == n_pieces ? file_bytes
                               : n_pieces == 2   ? file_bytes / 100 * ctx->bam_first_share_pct
-                                                : file_bytes / (uint64_t)(n_pieces + 1) * (uint64_t)(k + 1);
+                                                : file_bytes / parts_all * parts;
         ctx->staged_event[k] = nullptr;
         hipError_t e = hipEventCreateWithFlags(&ctx->staged_event[k], hipEventDisableTiming);
         ctx->staged_total = k + 1;
@@ -606,21 +629,107 @@ extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t f
     }
     ctx->staged_file = file;
     ctx->staged_bytes = file_bytes;
-    ctx->stage_thread = new (std::nothrow) std::thread([ctx, file, d_file, n_pieces] {
-        hipError_t e = hipSetDevice(ctx->device);
-        uint64_t copied = 0;
-        for (int k = 0; k < n_pieces; ++k) {
-            const uint64_t upto = ctx->staged_upto[k];
-            if (e == hipSuccess && upto > copied) e = hipMemcpyAsync(d_file + copied, file + copied, upto - copied, hipMemcpyHostToDevice, ctx->copy_stream);
-            if (e == hipSuccess) e = hipEventRecord(ctx->staged_event[k], ctx->copy_stream);
-            if (e != hipSuccess) {
-                ctx->staged_err.store((int)e);
-                ctx->staged_done.store(n_pieces, std::memory_order_release);  // nobody waits for a piece that will not come
-                return;
-            }
-            copied = upto;
-            ctx->staged_done.store(k + 1, std::memory_order_release);
+    // The upload.  hipMemcpyAsync from a pageable mapping moves ~17 GB/s here (one thread of the runtime copies into its
+    // staging buffers); bam_upload_threads threads copying slices of the mapping into a ring of pinned slots, each slot
+    // crossing by DMA as soon as it is full, move ~50 GB/s (tools/probe/h2d_probe.cpp: 281 MB in 5.6 instead of 15 ms).
+    int workers = file_bytes >= (1u << 20) ? (int)ctx->bam_upload_threads : 0;  // a small file: not worth the threads
+    if (workers > 0 && !ctx->pinned_ring) {
+        if (hipHostMalloc(&ctx->pinned_ring, kSlot * kSlots, hipHostMallocDefault) == hipSuccess)
+            ctx->pinned_ring_bytes = kSlot * kSlots;
+        else {
+            (void)hipGetLastError();
+            ctx->pinned_ring = nullptr;
+            workers = 0;  // no pinned memory to be had: the plain copy
         }
+    }
+    if (workers > 0)  // a piece ends where a slot does
+        for (int k = 0; k + 1 < n_pieces; ++k) ctx->staged_upto[k] = ctx->staged_upto[k] / kSlot * kSlot;
+    char* const ring = (char*)ctx->pinned_ring;
+    ctx->stage_thread = new (std::nothrow) std::thread([ctx, file, file_bytes, d_file, n_pieces, workers, ring] {
+        hipError_t e = hipSetDevice(ctx->device);
+        auto give_up = [&](hipError_t err) {
+            ctx->staged_err.store((int)err);
+            ctx->staged_done.store(n_pieces, std::memory_order_release);  // nobody waits for a piece that will not come
+        };
+        if (e != hipSuccess) return give_up(e);
+        if (workers <= 0) {
+            uint64_t copied = 0;
+            for (int k = 0; k < n_pieces; ++k) {
+                const uint64_t upto = ctx->staged_upto[k];
+                if (upto > copied) e = hipMemcpyAsync(d_file + copied, file + copied, upto - copied, hipMemcpyHostToDevice, ctx->copy_stream);
+                if (e == hipSuccess) e = hipEventRecord(ctx->staged_event[k], ctx->copy_stream);
+                if (e != hipSuccess) return give_up(e);
+                copied = upto;
+                ctx->staged_done.store(k + 1, std::memory_order_release);
+            }
+            return;
+        }
+        // Worker w copies the w-th part of every chunk; a chunk is ready when every worker has done its part, and may be
+        // filled once the chunk kSlots before it has crossed (fill_limit).  This thread issues the DMAs and the pieces'
+        // events.  `stop` ends the workers early when a HIP call has failed.
+        const uint64_t n_chunks = (file_bytes + kSlot - 1) / kSlot;
+        std::vector<std::atomic<int>> ready(n_chunks);
+        for (auto& r : ready) r.store(0);
+        std::atomic<uint64_t> fill_limit{(uint64_t)kSlots};
+        std::atomic<bool> stop{false};
+        hipEvent_t slot_event[kSlots] = {};
+        for (hipEvent_t& ev : slot_event)
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        std::vector<std::thread> pool;
+        if (e == hipSuccess) {
+            try {
+                for (int w = 0; w < workers; ++w)
+                    pool.emplace_back([&, w] {
+                        for (uint64_t c = 0; c < n_chunks; ++c) {
+                            while (c >= fill_limit.load(std::memory_order_acquire)) {
+                                if (stop.load(std::memory_order_relaxed)) return;
+                                std::this_thread::yield();
+                            }
+                            const uint64_t lo = c * kSlot, len = std::min(kSlot, file_bytes - lo);
+                            const uint64_t a = len * (uint64_t)w / (uint64_t)workers, b = len * (uint64_t)(w + 1) / (uint64_t)workers;
+                            std::memcpy(ring + (c % kSlots) * kSlot + a, file + lo + a, b - a);
+                            ready[c].fetch_add(1, std::memory_order_release);
+                        }
+                    });
+            } catch (...) {
+                e = hipErrorOutOfMemory;
+            }
+        }
+        const int started = (int)pool.size();
+        uint64_t oldest = 0, n_issued = 0;
+        auto poll = [&] {
+            while (oldest < n_issued && hipEventQuery(slot_event[oldest % kSlots]) == hipSuccess) {
+                ++oldest;
+                fill_limit.store(oldest + kSlots, std::memory_order_release);
+            }
+        };
+        int piece = 0;
+        for (uint64_t c = 0; e == hipSuccess && started == workers && c < n_chunks; ++c) {
+            while (ready[c].load(std::memory_order_acquire) < workers) {
+                poll();
+                std::this_thread::yield();
+            }
+            const uint64_t lo = c * kSlot, len = std::min(kSlot, file_bytes - lo);
+            e = hipMemcpyAsync(d_file + lo, ring + (c % kSlots) * kSlot, len, hipMemcpyHostToDevice, ctx->copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(slot_event[c % kSlots], ctx->copy_stream);
+            n_issued = c + 1;
+            while (e == hipSuccess && piece < n_pieces && ctx->staged_upto[piece] <= lo + len) {
+                e = hipEventRecord(ctx->staged_event[piece], ctx->copy_stream);
+                if (e == hipSuccess) ctx->staged_done.store(++piece, std::memory_order_release);
+            }
+            poll();
+        }
+        stop.store(true);
+        for (std::thread& t : pool) t.join();
+        // the slots are this call's until their copies have left them; an empty file's pieces still get their events
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_stream);
+        while (e == hipSuccess && started == workers && piece < n_pieces) {
+            e = hipEventRecord(ctx->staged_event[piece], ctx->copy_stream);
+            if (e == hipSuccess) ctx->staged_done.store(++piece, std::memory_order_release);
+        }
+        for (hipEvent_t ev : slot_event)
+            if (ev) (void)hipEventDestroy(ev);
+        if (e != hipSuccess || started != workers) give_up(e != hipSuccess ? e : hipErrorOutOfMemory);
     });
     if (!ctx->stage_thread) {
         msq_bgzf_drop_staged(ctx);
@@ -655,6 +764,9 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
     if (!was_staged)
         if (int rc = msq_bgzf_stage_file(ctx, file, file_bytes)) return rc;
     if (!ctx->copy_stream) MSQ_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->side_stream) MSQ_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    for (hipEvent_t& ev : ctx->side_event)
+        if (!ev) MSQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const double t_staged = ms_since();
     msq_bam_dev* b = new (std::nothrow) msq_bam_dev;
     if (!b) {
@@ -662,6 +774,7 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
         return msq_fail(MSQ_ERR_NOMEM, "msq_bgzf_inflate_device: out of memory");
     }
     auto fail = [&](int code, const char* what, hipError_t e) {
+        (void)hipStreamSynchronize(ctx->side_stream);
         (void)hipStreamSynchronize(ctx->stream);
         msq_bgzf_drop_staged(ctx);
         free_bam_dev(b);
@@ -697,8 +810,11 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
     e = hipMemsetAsync(b->d_data + total, 0, MSQ_BAM_DATA_PAD, ctx->stream);
     if (e == hipSuccess && n_members) e = hipMemcpyAsync(d_members, members, n_members * sizeof(msq_bgzf_member), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0xFF, status_bytes, ctx->stream);
-    // every piece's members behind its copy.  (A wave may look up to two chunks past its member into bytes that have not
-    // arrived: bits no valid stream consumes.)
+    // every piece's members behind its copy, the pieces' kernels in turn on the context's stream and on the side stream.
+    // (A wave may look up to two chunks past its member into bytes that have not arrived: bits no valid stream consumes.)
+    if (e == hipSuccess) e = hipEventRecord(ctx->side_event[0], ctx->stream);  // the tables are in place
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->side_stream, ctx->side_event[0], 0);
+    bool side_used = false;
     uint64_t m0 = 0;
     for (int k = 0; e == hipSuccess && k < ctx->staged_total; ++k) {
         const bool last = k + 1 == ctx->staged_total;
@@ -712,14 +828,18 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
             e = (hipError_t)ctx->staged_err.load();
             break;
         }
-        e = hipStreamWaitEvent(ctx->stream, ctx->staged_event[k], 0);
+        hipStream_t on = (k & 1) ? ctx->side_stream : ctx->stream;
+        e = hipStreamWaitEvent(on, ctx->staged_event[k], 0);
         if (e == hipSuccess && m1 > m0) {
-            hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((m1 - m0 + 3) / 4)), dim3(256), 0, ctx->stream, (const uint32_t*)d_file, file_padded / 4,
+            side_used |= (k & 1) != 0;
+            hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((m1 - m0 + 3) / 4)), dim3(256), 0, on, (const uint32_t*)d_file, file_padded / 4,
                                (const msq_bgzf_member*)d_members + m0, (uint32_t)(m1 - m0), b->d_data, (uint32_t*)d_status + m0);
             e = hipGetLastError();
         }
         m0 = m1;
     }
+    if (e == hipSuccess && side_used) e = hipEventRecord(ctx->side_event[1], ctx->side_stream);
+    if (e == hipSuccess && side_used) e = hipStreamWaitEvent(ctx->stream, ctx->side_event[1], 0);
     const double t_issued = ms_since();
     if (e == hipSuccess && n_members) e = hipMemcpyAsync(status.data(), d_status, n_members * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -62,6 +62,7 @@ extern "C" int msq_ctx_create(int device, msq_ctx** out)
     c->no_merge = std::getenv("MSQ_NO_MERGE") != nullptr;
     c->no_haps = std::getenv("MSQ_NO_HAPS") != nullptr;
     if (const char* v = std::getenv("MSQ_BAM_FIRST_SHARE")) c->bam_first_share_pct = (uint64_t)std::min(99ll, std::max(1ll, strtoll(v, nullptr, 10)));
+    if (const char* v = std::getenv("MSQ_BAM_UPLOAD_THREADS")) c->bam_upload_threads = (uint64_t)std::min(16ll, std::max(0ll, strtoll(v, nullptr, 10)));
     if (const char* v = std::getenv("MSQ_BAM_PIECES")) c->bam_pieces = (uint64_t)std::max(1ll, strtoll(v, nullptr, 10));
     if (const char* v = std::getenv("MSQ_CARRIER_MIN_BATCHES")) c->carrier_min_batches = (int64_t)strtoll(v, nullptr, 10);
     *out = c;
@@ -126,6 +127,10 @@ extern "C" int msq_ctx_destroy(msq_ctx* ctx)
     msq_bgzf_drop_staged(ctx);
     if (ctx->d_bam_tables) (void)hipFree(ctx->d_bam_tables);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->pinned_ring) (void)hipHostFree(ctx->pinned_ring);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    for (hipEvent_t ev : ctx->side_event)
+        if (ev) (void)hipEventDestroy(ev);
     timing_release(ctx);
     delete ctx;
     return MSQ_OK;

@@ -136,6 +136,32 @@ def test_many_members_and_odd_payload_offsets(ctx):
         L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, 2)
 
 
+def test_large_image_crosses_in_ring_slots(ctx):
+    """A file image of more than the upload ring (8 pinned slots of 8 MB, filled by the library's copy threads and reused
+    as their DMAs complete; msq_bgzf_stage_file): every byte must arrive, in pieces and in one."""
+    rng = np.random.default_rng(23)
+    noise = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    parts, want = [], []
+    for i in range(1700):  # ~90 MB: stored blocks of noise (nothing to compress), every 7th member text at level 6
+        off = (i * 40093) % ((1 << 20) - 65280)
+        p = noise[off:off + 65280 - (i % 5)] if i % 7 else (b"record %d\t" % i) * 4000
+        parts.append(member(p, level=0 if i % 7 else 6))
+        want.append(p)
+    blob = b"".join(parts) + member(b"")
+    assert len(blob) > 80 << 20
+    members = scan(blob)
+    want = b"".join(want)
+    L = abi.lib()
+    try:
+        for pieces in (2, 1, 3):
+            abi.check(L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, pieces))
+            got = inflate_device(ctx, blob, members)
+            assert len(got) == len(want)
+            assert got == want, pieces
+    finally:
+        L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, 2)
+
+
 def test_bam_shaped_members(ctx, tmp_path):
     """Members the way a BAM writer makes them: 65280-byte payloads of records (packed bases, quality bytes, names, tags)
     at level 1 -- long literal runs that end in a length code with extra bits right at the edge of the speculative window
