@@ -180,33 +180,107 @@ inline bool InflateMember(const uint8_t* in, size_t in_len, uint8_t* out, size_t
 
 // BGZF (SAMv1 4.1): gzip members with FEXTRA holding the subfield 'B','C',2,BSIZE.  Where the members are and what
 // they inflate to; *total = the inflated stream's length.
-inline std::vector<BgzfBlock> ScanBgzf(const MappedFile& file, size_t* total)
+// One member at `off`: its block (out_off left 0) and its size in the file.  Nothing in the header is trusted: the extra
+// field must lie inside the file, every subfield inside the extra field, and the block must hold its header, the 8-byte
+// trailer (CRC32, ISIZE) and end inside the file.
+inline BgzfBlock ScanBgzfMember(const MappedFile& file, size_t off, size_t* bsizeOut)
+{
+    if (off + 18 > file.size() || file[off] != 31 || file[off + 1] != 139 || file[off + 2] != 8 || !(file[off + 3] & 4))
+        throw std::runtime_error("not a BGZF block");
+    const size_t xlen = U16(&file[off + 10]);
+    const size_t xend = off + 12 + xlen;
+    if (xend + 8 > file.size()) throw std::runtime_error("truncated BGZF block");
+    size_t x = off + 12, bsize = 0;
+    while (x + 4 <= xend) {
+        const size_t slen = U16(&file[x + 2]);
+        if (x + 4 + slen > xend) throw std::runtime_error("truncated BGZF block");
+        if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) bsize = (size_t)U16(&file[x + 4]) + 1;
+        x += 4 + slen;
+    }
+    if (!bsize || bsize < 12 + xlen + 8 || off + bsize > file.size()) throw std::runtime_error("truncated BGZF block");
+    *bsizeOut = bsize;
+    return BgzfBlock{xend, off + bsize - 8 - xend, 0, (size_t)U32(&file[off + bsize - 4])};
+}
+
+inline std::vector<BgzfBlock> ScanBgzfSerial(const MappedFile& file, size_t* total)
 {
     std::vector<BgzfBlock> blocks;
     size_t off = 0, out = 0;
     while (off < file.size()) {
-        if (off + 18 > file.size() || file[off] != 31 || file[off + 1] != 139 || file[off + 2] != 8 || !(file[off + 3] & 4))
-            throw std::runtime_error("not a BGZF block");
-        // nothing in the header is trusted: the extra field must lie inside the file, every subfield inside the extra
-        // field, and the block must hold its header, the 8-byte trailer (CRC32, ISIZE) and end inside the file
-        const size_t xlen = U16(&file[off + 10]);
-        const size_t xend = off + 12 + xlen;
-        if (xend + 8 > file.size()) throw std::runtime_error("truncated BGZF block");
-        size_t x = off + 12, bsize = 0;
-        while (x + 4 <= xend) {
-            const size_t slen = U16(&file[x + 2]);
-            if (x + 4 + slen > xend) throw std::runtime_error("truncated BGZF block");
-            if (file[x] == 'B' && file[x + 1] == 'C' && slen == 2) bsize = (size_t)U16(&file[x + 4]) + 1;
-            x += 4 + slen;
-        }
-        if (!bsize || bsize < 12 + xlen + 8 || off + bsize > file.size()) throw std::runtime_error("truncated BGZF block");
-        const size_t payload = xend;
-        const size_t isize = U32(&file[off + bsize - 4]);
-        blocks.push_back({payload, off + bsize - 8 - payload, out, isize});
-        out += isize;
+        size_t bsize = 0;
+        BgzfBlock k = ScanBgzfMember(file, off, &bsize);
+        k.out_off = out;
+        blocks.push_back(k);
+        out += k.out_len;
         off += bsize;
     }
     *total = out;
+    return blocks;
+}
+
+// The members form a chain (each header holds its block's size), and walking it is a page fault or a cache miss per
+// member: 4.4 ms for the 7000 members of a 280 MB file.  With threads, the file is cut into ranges; each range but the
+// first starts at the first place in it that looks like a member the way every BAM writer makes them (the 16 fixed
+// bytes of a gzip header with the one BC subfield), and is walked by its own thread up to the start of the next range.
+// A range whose walk ends exactly on the next range's start proves that start to be a real member, given its own is
+// (the first range starts at the file's start): then the result is the serial scan's, block for block.  Anything else
+// -- a look-alike inside compressed data, a writer with other extra fields, a broken file -- and the serial scan decides.
+inline std::vector<BgzfBlock> ScanBgzf(const MappedFile& file, size_t* total, unsigned threads = 1, bool* inRanges = nullptr)
+{
+    if (inRanges) *inRanges = false;
+    const unsigned ranges = std::min<unsigned>(threads, 8);
+    if (ranges < 2 || file.size() < (size_t(8) << 20)) return ScanBgzfSerial(file, total);
+    static const uint8_t kHead[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0};
+    std::vector<size_t> start(ranges + 1, 0);
+    start[ranges] = file.size();
+    for (unsigned r = 1; r < ranges; ++r) {
+        const size_t from = file.size() / ranges * r, upto = std::min(file.size() - 16, from + (size_t(1) << 17));
+        size_t at = from;
+        while (at < upto && std::memcmp(&file[at], kHead, 16) != 0) {
+            const void* next = std::memchr(&file[at + 1], 31, upto - at);
+            at = next ? size_t(static_cast<const uint8_t*>(next) - &file[0]) : upto;
+        }
+        if (at >= upto) return ScanBgzfSerial(file, total);
+        start[r] = at;
+    }
+    std::vector<std::vector<BgzfBlock>> part(ranges);
+    std::vector<char> good(ranges, 0);
+    std::vector<std::thread> pool;
+    for (unsigned r = 0; r < ranges; ++r)
+        pool.emplace_back([&, r] {
+            try {
+                size_t off = start[r], out = 0;
+                part[r].reserve((start[r + 1] - start[r]) / 16384 + 16);
+                while (off < start[r + 1]) {
+                    size_t bsize = 0;
+                    BgzfBlock k = ScanBgzfMember(file, off, &bsize);
+                    k.out_off = out;
+                    part[r].push_back(k);
+                    out += k.out_len;
+                    off += bsize;
+                }
+                good[r] = off == start[r + 1];
+            } catch (...) {  // the serial scan will say what is wrong, if anything is
+            }
+        });
+    for (std::thread& t : pool) t.join();
+    size_t n = 0;
+    for (unsigned r = 0; r < ranges; ++r) {
+        if (!good[r]) return ScanBgzfSerial(file, total);
+        n += part[r].size();
+    }
+    std::vector<BgzfBlock> blocks;
+    blocks.reserve(n);
+    size_t out = 0;
+    for (unsigned r = 0; r < ranges; ++r) {
+        for (BgzfBlock k : part[r]) {
+            k.out_off += out;
+            blocks.push_back(k);
+        }
+        if (!part[r].empty()) out = blocks.back().out_off + blocks.back().out_len;
+    }
+    *total = out;
+    if (inRanges) *inRanges = true;
     return blocks;
 }
 
@@ -214,7 +288,7 @@ inline std::vector<BgzfBlock> ScanBgzf(const MappedFile& file, size_t* total)
 inline Bytes InflateBgzf(const MappedFile& file, unsigned threads)
 {
     size_t out = 0;
-    const std::vector<BgzfBlock> blocks = ScanBgzf(file, &out);
+    const std::vector<BgzfBlock> blocks = ScanBgzf(file, &out, threads);
     Bytes data(out);
     const Deflater* fast = Deflater::Get();
     auto work = [&](size_t first, size_t step) {
@@ -489,7 +563,7 @@ struct BamUtils
         size_t fileBytes = 0, bamBytes = 0;
         uint64_t nRecords = 0, nKept = 0;
         std::vector<std::pair<std::string, std::string>> readGroups;
-        Clock::time_point t1, t2;
+        Clock::time_point t1, t2, tMapped, tStaging, tScanned;
         uint64_t first = 0;
         int32_t nRef = 0;
         {
@@ -505,8 +579,11 @@ struct BamUtils
                 msq_ctx* ctx;
                 ~Staging() { (void)msq_bgzf_stage_file(ctx, nullptr, 0); }  // nothing to forget once the inflate call has taken it
             } staging{ctx};
+            tMapped = Clock::now();
             if (file.size()) (void)msq_bgzf_stage_file(ctx, file.data(), file.size());  // an error repeats in the inflate call
-            const std::vector<BgzfBlock> blocks = ScanBgzf(file, &bamBytes);
+            tStaging = Clock::now();
+            const std::vector<BgzfBlock> blocks = ScanBgzf(file, &bamBytes, threads);
+            tScanned = Clock::now();
             std::vector<msq_bgzf_member> members(blocks.size());
             for (size_t b = 0; b < blocks.size(); ++b)
                 members[b] = msq_bgzf_member{(uint64_t)blocks[b].in_off, (uint64_t)blocks[b].out_off, (uint32_t)blocks[b].in_len, (uint32_t)blocks[b].out_len};
@@ -648,8 +725,8 @@ struct BamUtils
         };
         if (usedDevice) *usedDevice = true;
         if (std::getenv("MSQ_BAM_TRACE"))
-            std::fprintf(stderr, "BamToReadSourceDevice: map + scan + header %.2f ms, inflate %.2f, index %.2f, records + names %.2f, source %.2f\n",
-                         1e3 * secs(t0, t1), 1e3 * secs(t1, t2), 1e3 * secs(t3, t4), 1e3 * secs(t4, t5), 1e3 * secs(t5, Clock::now()));
+            std::fprintf(stderr, "BamToReadSourceDevice: map %.2f ms, staging started %.2f, scan %.2f, header %.2f, inflate %.2f, index %.2f, records + names %.2f, source %.2f\n",
+                         1e3 * secs(t0, tMapped), 1e3 * secs(tMapped, tStaging), 1e3 * secs(tStaging, tScanned), 1e3 * secs(tScanned, t1), 1e3 * secs(t1, t2), 1e3 * secs(t3, t4), 1e3 * secs(t4, t5), 1e3 * secs(t5, Clock::now()));
         if (timings) {
             timings->read = secs(t0, t1);
             timings->inflate = secs(t1, t2);

@@ -27,8 +27,35 @@ int main(int argc, char** argv)
         if (!std::strcmp(argv[i], "--top-pad") && i + 1 < argc) mallopt(M_TOP_PAD, std::atoi(argv[++i]) << 20);  // experiment: arena growth step, MB
         if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)std::atoi(argv[++i]);
     }
+    bool scan_check = false;
+    for (int i = 4; i < argc; ++i)
+        if (!std::strcmp(argv[i], "--scan-check")) scan_check = true;
     try {
         IO::BamTimings tm;
+        if (scan_check) {  // the BGZF member table found in ranges by several threads against the serial walk's
+            using namespace IO::detail;
+            const MappedFile file(argv[1]);
+            size_t total_serial = 0, total_ranges = 0;
+            bool in_ranges = false;
+            std::string error_serial, error_ranges;
+            std::vector<BgzfBlock> serial, ranges;
+            try {
+                serial = ScanBgzfSerial(file, &total_serial);
+            } catch (const std::exception& e) {
+                error_serial = e.what();
+            }
+            try {
+                ranges = ScanBgzf(file, &total_ranges, threads, &in_ranges);
+            } catch (const std::exception& e) {
+                error_ranges = e.what();
+            }
+            bool same = serial.size() == ranges.size() && total_serial == total_ranges && error_serial == error_ranges;
+            for (size_t b = 0; same && b < serial.size(); ++b)
+                same = serial[b].in_off == ranges[b].in_off && serial[b].in_len == ranges[b].in_len && serial[b].out_off == ranges[b].out_off &&
+                       serial[b].out_len == ranges[b].out_len;
+            std::printf("SCAN members %zu total %zu same %d in_ranges %d error '%s'\n", serial.size(), total_serial, (int)same, (int)in_ranges, error_serial.c_str());
+            return same ? 0 : 1;
+        }
         if (direct) {  // BAM records decoded straight into the device packer's staging: no ArrayRead objects
             const Juliet::ErrorEstimates error("S/P2-C2");
             Juliet::JulietSettings s;

@@ -226,6 +226,77 @@ def test_block_sizes_and_threads(tmp_path, ref):
         assert rc == 0 and got == want
 
 
+def _member(payload, level=6, extra=b""):
+    """A BGZF block; `extra`: further subfields in the gzip extra field, before the BC one."""
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = co.compress(payload) + co.flush()
+    bsize = 12 + len(extra) + 6 + len(comp) + 8
+    assert bsize <= 65536
+    return (struct.pack("<BBBBIBBH", 31, 139, 8, 4, 0, 0, 255, 6 + len(extra)) + extra + b"BC" + struct.pack("<HH", 2, bsize - 1) + comp
+            + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+
+
+def _scan_check(path, threads):
+    out = subprocess.run([BIN, path, "0", "0", "--scan-check", "--threads", str(threads)], capture_output=True, text=True, timeout=300)
+    t = out.stdout.split()
+    assert t[0] == "SCAN", out.stdout + out.stderr
+    return out.returncode, dict(members=int(t[2]), total=int(t[4]), same=int(t[6]), in_ranges=int(t[8]), error=out.stdout.split("error ")[1].strip())
+
+
+def test_member_scan_in_ranges_equals_the_serial_walk(tmp_path):
+    """ScanBgzf with threads cuts the file into ranges that start at look-alikes of a member header and walks them side by
+    side; its table must be the serial walk's, block for block, whatever the file holds: look-alikes inside stored data
+    (the range whose walk does not land on the next start sends the scan back to the serial walk), members with further
+    extra subfields (no look-alike to be found), a file cut short (the serial walk's error), small files (serial)."""
+    rng = np.random.default_rng(31)
+    noise = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    head = bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0]) + b"BC" + bytes([2, 0])
+
+    def build(n, planted=False, extra_every=0):
+        parts = []
+        for i in range(n):
+            off = (i * 52361) % ((1 << 20) - 65000)
+            p = noise[off:off + 60000 + (i * 37) % 5000]
+            if planted and i % 3 == 0:  # stored blocks full of member headers that are none: BSIZE fields pointing anywhere
+                p = (head + struct.pack("<H", (i * 977) % 65536) + noise[off:off + 46]) * 900
+            parts.append(_member(p, level=0 if (planted and i % 3 == 0) else 1, extra=b"XY\x04\x00abcd" if extra_every and i % extra_every == 0 else b""))
+        return b"".join(parts) + _member(b"")
+
+    path = str(tmp_path / "scan.bgzf")
+    # plain: every range start is a member; walked in ranges
+    blob = build(400)
+    assert len(blob) > 16 << 20
+    open(path, "wb").write(blob)
+    for threads in (1, 2, 3, 8, 16):
+        rc, r = _scan_check(path, threads)
+        assert rc == 0 and r["same"] == 1 and r["members"] == 401 and r["in_ranges"] == (threads > 1), (threads, r)
+    # look-alikes: whatever the ranges find, the table is the serial walk's
+    blob = build(400, planted=True)
+    open(path, "wb").write(blob)
+    seen = set()
+    for threads in (2, 3, 4, 5, 6, 7, 8):
+        rc, r = _scan_check(path, threads)
+        assert rc == 0 and r["same"] == 1 and r["members"] == 401, (threads, r)
+        seen.add(r["in_ranges"])
+    assert 0 in seen  # some cut did start on a look-alike
+    # members with another subfield in front of BC: nothing looks like the usual header, the serial walk does it
+    open(path, "wb").write(build(400, extra_every=1))
+    rc, r = _scan_check(path, 8)
+    assert rc == 0 and r["same"] == 1 and r["in_ranges"] == 0 and r["members"] == 401
+    # ... or only some of them do
+    open(path, "wb").write(build(400, extra_every=5))
+    rc, r = _scan_check(path, 8)
+    assert rc == 0 and r["same"] == 1 and r["members"] == 401
+    # a file cut short: the same error either way
+    open(path, "wb").write(build(400)[:-40000])
+    rc, r = _scan_check(path, 8)
+    assert rc == 0 and r["same"] == 1 and r["error"] == "'truncated BGZF block'" and r["in_ranges"] == 0
+    # a small file: serial
+    open(path, "wb").write(build(40))
+    rc, r = _scan_check(path, 8)
+    assert rc == 0 and r["same"] == 1 and r["in_ranges"] == 0 and r["members"] == 41
+
+
 def test_empty_and_broken_files(tmp_path, ref):
     path = str(tmp_path / "e.bam")
     write_bam(path, [], len(ref))
