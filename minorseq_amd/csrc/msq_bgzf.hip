@@ -7,14 +7,17 @@
 //   * The compressed bits are wave-uniform state: a 64-bit bit buffer in scalar registers, refilled 32 bits at a
 //     time from a VGPR that holds the next 256 input bytes (lane i = dword i, read with v_readlane; the chunk after
 //     it is loaded a whole chunk ahead), so the decode loop never waits for global memory.
-//   * Huffman decode: one LDS lookup per symbol in a 2^10 (literal/length) or 2^9 (distance) entry table of
-//     (symbol << 4 | length); longer codes take the canonical first-code / count compare per length.  The tables are
-//     built by the 64 lanes (counts by LDS atomics, canonical order by ballots, every lane fills its 16 entries).
+//   * Huffman decode: one LDS lookup per symbol in a 2^10 (literal/length) or 2^9 (distance) entry table whose entries
+//     hold the answer (a literal's byte; a length's base and extra bits; a distance's top bits and extra bits); longer
+//     codes take the canonical first-code / count compare per length.  The tables are built by the 64 lanes (counts by
+//     LDS atomics, canonical order by ballots, every lane fills its 16 entries).
 //   * Literals are decoded speculatively: lane k looks up the code that would start k bits into the bit buffer, the
-//     wave walks the chain of real code starts through those 64 entries with v_readlane, and the window's literals
-//     leave in one store (one LDS access and ~60 instructions per ~5 literals; a kernel of this shape is bound by the
-//     CU's instruction issue, one wave-instruction per cycle, not by memory).  A match is copied by all lanes at once (source index modulo the distance where the match overlaps itself)
-//     straight in HBM: the wave reads what it has just stored, which the vector memory pipeline keeps in order.
+//     wave walks the chain of real code starts through those 64 entries with v_readlane (four instructions per literal),
+//     and the window's literals leave in one store.  A kernel of this shape is bound by the CU's scalar unit -- one
+//     instruction per cycle and CU -- not by memory, and its time follows the count of scalar instructions one for one:
+//     the hot loop is hand-written where the compiler spent them (see the window's asm statement, inflate_fail, the
+//     entry formats).  A match is copied by all lanes at once (source index modulo the distance where the match overlaps
+//     itself) straight in HBM: the wave reads what it has just stored, which the vector memory pipeline keeps in order.
 // Byte work, bit-exact: the test is equality with zlib's output (tests/test_gpu_bgzf.py).  A member that zlib would
 // refuse (invalid block type, stored length check, over-subscribed or incomplete code, repeat without a previous
 // length, missing end-of-block code, invalid symbol, distance too far back, input or output exhausted) is refused
@@ -416,7 +419,8 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                     // the compiler's version of this part took about twice as many).  The chain walk, four instructions
                     // per literal: every offset visited gets its bit in `starts`; s_min both copies the next offset into
                     // the lane select (a VALU-written SGPR as lane select needs wait states, a SALU-written one none)
-                    // and compares it with the window's end (SCC = the first operand is the smaller one).  The walk
+                    // and compares it with the window's end (SCC = the first operand is the smaller one); unrolled six
+                    // times, so that the walk of a usual window takes no branch but the one out of it.  The walk
                     // ends behind the window (next <= 64 - 5) or at a non-literal (next = 64, its offset the last bit
                     // set, which is then taken out again and its entry read into e).  Then the literals leave in one
                     // store: exec = starts, a lane's rank among the starts is v_mbcnt of exec, and a byte at or beyond
@@ -431,7 +435,28 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                         "s_bitset1_b64 %[st], %[k]\n\t"
                         "v_readlane_b32 %[t], %[onward], %[k]\n\t"
                         "s_min_u32 %[k], %[t], %[K1]\n\t"
-                        "s_cbranch_scc1 1b\n\t"
+                        "s_cbranch_scc0 3f\n\t"
+                        "s_bitset1_b64 %[st], %[k]\n\t"
+                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+                        "s_min_u32 %[k], %[t], %[K1]\n\t"
+                        "s_cbranch_scc0 3f\n\t"
+                        "s_bitset1_b64 %[st], %[k]\n\t"
+                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+                        "s_min_u32 %[k], %[t], %[K1]\n\t"
+                        "s_cbranch_scc0 3f\n\t"
+                        "s_bitset1_b64 %[st], %[k]\n\t"
+                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+                        "s_min_u32 %[k], %[t], %[K1]\n\t"
+                        "s_cbranch_scc0 3f\n\t"
+                        "s_bitset1_b64 %[st], %[k]\n\t"
+                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+                        "s_min_u32 %[k], %[t], %[K1]\n\t"
+                        "s_cbranch_scc0 3f\n\t"
+                        "s_bitset1_b64 %[st], %[k]\n\t"
+                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+                        "s_min_u32 %[k], %[t], %[K1]\n\t"
+                        "s_cbranch_scc1 1b\n"
+                        "3:\n\t"
                         "s_mov_b32 %[e], 0\n\t"
                         "s_cmp_lt_u32 %[t], 64\n\t"
                         "s_cbranch_scc1 2f\n\t"
@@ -586,14 +611,13 @@ void msq_bgzf_drop_staged(msq_ctx* ctx)
     ctx->staged_bytes = 0;
 }
 
-// The file image on its way into the context's scratch: pieces on the copy stream, an event behind each.  The copy of a
-// pageable mapping keeps its thread busy (and faults the mapping's pages in), so it runs on a thread of the library's own
-// and this call returns at once: the caller scans the BGZF headers meanwhile, and msq_bgzf_inflate_device launches every
-// piece's kernel as soon as that piece is on its way (it stages the image itself when nobody has).
-// Two pieces, the first a third of the file: a kernel takes ~6 ms however few members it has (one member is one wave,
-// ~14 000 dependent windows of ~1100 cycles) and 2 us per member once the chip's issue slots are full (10^5 reads:
-// 13.8 ms), so the first piece's kernel should end when the second piece's copy does; kernels of several streams did not
-// overlap (measured: 18 pieces of 16 MB on four streams 46 ms after the copies, 4 pieces on one stream 26 ms).
+// The file image on its way into the context's scratch: pieces on the copy stream, an event behind each.  The copies are
+// fed by threads of the library's own and this call returns at once: the caller scans the BGZF headers meanwhile, and
+// msq_bgzf_inflate_device launches every piece's kernel behind that piece's event (it stages the image itself when
+// nobody has).  Two pieces, 40 % and 60 %: a kernel takes ~5.5 ms however few members it has (one member is one wave,
+// ~8000 dependent windows and 6400 matches with a memory round trip each) and 1.4 us per member once the chip's issue
+// slots are full (10^5 reads: 9.7 ms), so more pieces cost more than they hide (tools/bam_share_ab.sh); the pieces'
+// kernels run side by side on two streams (tools/bam_timeline.sh).
 extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t file_bytes)
 {
     if (!ctx || (file_bytes && !file)) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_stage_file: NULL argument");
