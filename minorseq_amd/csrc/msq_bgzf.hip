@@ -305,6 +305,102 @@ __device__ inline void inflate_fail(uint32_t* status, uint32_t code, int lane)
 }
 #define INF_FAIL(code) inflate_fail(status, (code), lane)
 
+// One window of the literal decode, in two halves (see inflate_member for why they can be apart).
+//   Speculative decode: lane k looks up the code that WOULD start k bits on; the wave then walks the chain of real code
+// starts through those entries with v_readlane (no memory in the chain) and all literals of the window leave in one
+// store.  One LDS access per ~5 literals instead of one each.
+//   Both halves are hand-written (the kernel is bound by the issue of scalar instructions, and the compiler's version
+// took about twice as many).  The chain walk, four instructions per literal: every offset visited gets its bit in
+// `starts`; s_min both copies the next offset into the lane select (a VALU-written SGPR as lane select needs wait
+// states, a SALU-written one none) and compares it with the window's end (SCC = the first operand is the smaller one);
+// unrolled six times, so that the walk of a usual window takes no branch but the one out of it.  The walk ends behind
+// the window (next <= 64 - 5) or at a non-literal (next = 64, its offset the last bit set, which is then taken out again
+// and its entry read into e).
+struct Window {
+    uint64_t starts;  // the offsets literals start at
+    uint32_t mine;    // lane k: the entry of the code that would start k bits on
+    uint32_t next;    // the bits the window takes: up to the next window's first code, or up to the non-literal
+    uint32_t n;       // literals
+    uint32_t e;       // the non-literal's entry, 0 when the window ended on its length
+};
+
+__device__ __forceinline__ void window_walk(BitReader& br, const uint16_t* lit, int lane, Window& w)
+{
+    br.refill();
+    const uint32_t K1 = (uint32_t)br.cnt - 14u;  // a code that starts at an offset < K1 has all its bits (and 5 to spare) in buf
+    w.mine = lit[(uint32_t)(br.buf >> lane) & ((1u << LIT_BITS) - 1u)];
+    // where the chain goes on from offset `lane`: behind the literal that starts there, or to 64 when the code there is
+    // no literal (or no code of the primary table)
+    const uint32_t onward = (w.mine & kNotLiteral) ? 64u : (uint32_t)lane + (w.mine & 15u);
+    asm volatile(
+        "s_mov_b64 %[st], 0\n\t"
+        "s_mov_b32 %[k], 0\n"
+        "1:\n\t"
+        "s_bitset1_b64 %[st], %[k]\n\t"
+        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+        "s_min_u32 %[k], %[t], %[K1]\n\t"
+        "s_cbranch_scc0 3f\n\t"
+        "s_bitset1_b64 %[st], %[k]\n\t"
+        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+        "s_min_u32 %[k], %[t], %[K1]\n\t"
+        "s_cbranch_scc0 3f\n\t"
+        "s_bitset1_b64 %[st], %[k]\n\t"
+        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+        "s_min_u32 %[k], %[t], %[K1]\n\t"
+        "s_cbranch_scc0 3f\n\t"
+        "s_bitset1_b64 %[st], %[k]\n\t"
+        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+        "s_min_u32 %[k], %[t], %[K1]\n\t"
+        "s_cbranch_scc0 3f\n\t"
+        "s_bitset1_b64 %[st], %[k]\n\t"
+        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+        "s_min_u32 %[k], %[t], %[K1]\n\t"
+        "s_cbranch_scc0 3f\n\t"
+        "s_bitset1_b64 %[st], %[k]\n\t"
+        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
+        "s_min_u32 %[k], %[t], %[K1]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "3:\n\t"
+        "s_mov_b32 %[e], 0\n\t"
+        "s_cmp_lt_u32 %[t], 64\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_flbit_i32_b64 %[t], %[st]\n\t"
+        "s_xor_b32 %[t], %[t], 63\n\t"
+        "s_bitset0_b64 %[st], %[t]\n\t"
+        "v_readlane_b32 %[e], %[mine], %[t]\n"
+        "2:\n\t"
+        "s_bcnt1_i32_b64 %[k], %[st]"
+        : [st] "=&s"(w.starts), [k] "=&s"(w.n), [t] "=&s"(w.next), [e] "=&s"(w.e)
+        : [onward] "v"(onward), [mine] "v"(w.mine), [K1] "s"(K1)
+        : "scc");
+}
+
+// ... and the literals leave in one store: exec = starts, a lane's rank among the starts is v_mbcnt of exec, and a byte at
+// or beyond out_len is not written (pos runs on and the member fails at its next match or at its end, as it does in
+// zlib); last the bits walked over are dropped.
+__device__ __forceinline__ void window_emit(BitReader& br, const Window& w, uint8_t* dst, uint32_t& pos, uint32_t out_len)
+{
+    uint64_t save;
+    uint32_t vaddr, vdata;
+    asm volatile(
+        "s_mov_b64 %[save], exec\n\t"
+        "s_mov_b64 exec, %[st]\n\t"
+        "v_mbcnt_lo_u32_b32 %[va], exec_lo, 0\n\t"
+        "v_mbcnt_hi_u32_b32 %[va], exec_hi, %[va]\n\t"
+        "v_add_u32_e32 %[va], %[pos], %[va]\n\t"
+        "v_lshrrev_b32_e32 %[vd], 4, %[mine]\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[outlen], %[va]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "global_store_byte %[va], %[vd], %[dst]\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "s_add_u32 %[pos], %[pos], %[n]\n\t"
+        "s_lshr_b64 %[buf], %[buf], %[t]\n\t"
+        "s_sub_u32 %[cnt], %[cnt], %[t]"
+        : [save] "=&s"(save), [va] "=&v"(vaddr), [vd] "=&v"(vdata), [pos] "+s"(pos), [buf] "+s"(br.buf), [cnt] "+s"(br.cnt)
+        : [st] "s"(w.starts), [n] "s"(w.n), [t] "s"(w.next), [mine] "v"(w.mine), [outlen] "s"(out_len), [dst] "s"(dst)
+        : "scc", "vcc", "memory");
+}
+
 __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t file_words, const msq_bgzf_member mem,
                                    uint8_t* __restrict__ out, WaveLds& S, int lane, uint32_t* __restrict__ status)
 {
@@ -319,8 +415,6 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
     br.lane = lane;
     br.init(mem.in_off);
     uint32_t pos = 0;  // bytes written
-    bool pend = false;  // a match's bytes are loaded (pend_byte, lane by lane) and not yet stored (at pend_at)
-    uint32_t pend_at = 0, pend_byte = 0;
     bool fixed_ready = false;
     for (;;) {
         if (br.bit_pos() + 3 > end_bit) INF_FAIL(INF_ERR_INPUT);
@@ -403,88 +497,23 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 if (const uint32_t e = uni(build_code<DIST_BITS, CODE_DIST>(S.lens + n_lit, n_dist, S.dist, S.sorted_dist, &S.cs_dist, S.cnt, true, lane))) INF_FAIL(e);
                 fixed_ready = btype == 1;
             }
+            // The symbol loop: windows of literals until one ends at a non-literal (w.e), then that length / distance
+            // pair.  A match of up to 64 bytes (nearly all are) loads its source bytes, and while they are on their way
+            // the NEXT window is looked up and walked; then the match's bytes are stored, then the window's literals
+            // (behind the match: other addresses).  Alone in its SIMD a wave spends most of its time in the matches'
+            // memory round trips; this puts ~60 instructions into each.  `have`: w is that next window, emitted already.
+            bool have = false;
+            Window w;
             for (;;) {
-                uint32_t e;
-                for (;;) {  // a run of literals: the loop the kernel lives in
-                    // Speculative decode: lane k looks up the code that WOULD start k bits on; the wave then walks the
-                    // chain of real code starts through those entries with v_readlane (no memory in the chain) and all
-                    // literals of the window leave in one store.  One LDS access per ~5 literals instead of one each.
-                    br.refill();
-                    const uint32_t K1 = (uint32_t)br.cnt - 14u;  // a code that starts at an offset < K1 has all its bits (and 5 to spare) in buf
-                    const uint32_t mine = S.lit[(uint32_t)(br.buf >> lane) & ((1u << LIT_BITS) - 1u)];
-                    // where the chain goes on from offset `lane`: behind the literal that starts there, or to 64 when the code
-                    // there is no literal (or no code of the primary table)
-                    const uint32_t onward = (mine & kNotLiteral) ? 64u : (uint32_t)lane + (mine & 15u);
-                    // The rest of the window is hand-written (the kernel is bound by the issue of scalar instructions, and
-                    // the compiler's version of this part took about twice as many).  The chain walk, four instructions
-                    // per literal: every offset visited gets its bit in `starts`; s_min both copies the next offset into
-                    // the lane select (a VALU-written SGPR as lane select needs wait states, a SALU-written one none)
-                    // and compares it with the window's end (SCC = the first operand is the smaller one); unrolled six
-                    // times, so that the walk of a usual window takes no branch but the one out of it.  The walk
-                    // ends behind the window (next <= 64 - 5) or at a non-literal (next = 64, its offset the last bit
-                    // set, which is then taken out again and its entry read into e).  Then the literals leave in one
-                    // store: exec = starts, a lane's rank among the starts is v_mbcnt of exec, and a byte at or beyond
-                    // out_len is not written (pos runs on and the member fails at its next match or at its end, as it
-                    // does in zlib); last the bits walked over are dropped.
-                    uint64_t starts, save;
-                    uint32_t k, next, vaddr, vdata;
-                    asm volatile(
-                        "s_mov_b64 %[st], 0\n\t"
-                        "s_mov_b32 %[k], 0\n"
-                        "1:\n\t"
-                        "s_bitset1_b64 %[st], %[k]\n\t"
-                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
-                        "s_min_u32 %[k], %[t], %[K1]\n\t"
-                        "s_cbranch_scc0 3f\n\t"
-                        "s_bitset1_b64 %[st], %[k]\n\t"
-                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
-                        "s_min_u32 %[k], %[t], %[K1]\n\t"
-                        "s_cbranch_scc0 3f\n\t"
-                        "s_bitset1_b64 %[st], %[k]\n\t"
-                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
-                        "s_min_u32 %[k], %[t], %[K1]\n\t"
-                        "s_cbranch_scc0 3f\n\t"
-                        "s_bitset1_b64 %[st], %[k]\n\t"
-                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
-                        "s_min_u32 %[k], %[t], %[K1]\n\t"
-                        "s_cbranch_scc0 3f\n\t"
-                        "s_bitset1_b64 %[st], %[k]\n\t"
-                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
-                        "s_min_u32 %[k], %[t], %[K1]\n\t"
-                        "s_cbranch_scc0 3f\n\t"
-                        "s_bitset1_b64 %[st], %[k]\n\t"
-                        "v_readlane_b32 %[t], %[onward], %[k]\n\t"
-                        "s_min_u32 %[k], %[t], %[K1]\n\t"
-                        "s_cbranch_scc1 1b\n"
-                        "3:\n\t"
-                        "s_mov_b32 %[e], 0\n\t"
-                        "s_cmp_lt_u32 %[t], 64\n\t"
-                        "s_cbranch_scc1 2f\n\t"
-                        "s_flbit_i32_b64 %[t], %[st]\n\t"
-                        "s_xor_b32 %[t], %[t], 63\n\t"
-                        "s_bitset0_b64 %[st], %[t]\n\t"
-                        "v_readlane_b32 %[e], %[mine], %[t]\n"
-                        "2:\n\t"
-                        "s_bcnt1_i32_b64 %[k], %[st]\n\t"
-                        "s_mov_b64 %[save], exec\n\t"
-                        "s_mov_b64 exec, %[st]\n\t"
-                        "v_mbcnt_lo_u32_b32 %[va], exec_lo, 0\n\t"
-                        "v_mbcnt_hi_u32_b32 %[va], exec_hi, %[va]\n\t"
-                        "v_add_u32_e32 %[va], %[pos], %[va]\n\t"
-                        "v_lshrrev_b32_e32 %[vd], 4, %[mine]\n\t"
-                        "v_cmp_gt_u32_e32 vcc, %[outlen], %[va]\n\t"
-                        "s_and_b64 exec, exec, vcc\n\t"
-                        "global_store_byte %[va], %[vd], %[dst]\n\t"
-                        "s_mov_b64 exec, %[save]\n\t"
-                        "s_add_u32 %[pos], %[pos], %[k]\n\t"
-                        "s_lshr_b64 %[buf], %[buf], %[t]\n\t"
-                        "s_sub_u32 %[cnt], %[cnt], %[t]"
-                        : [st] "=&s"(starts), [k] "=&s"(k), [t] "=&s"(next), [e] "=&s"(e), [save] "=&s"(save), [va] "=&v"(vaddr),
-                          [vd] "=&v"(vdata), [pos] "+s"(pos), [buf] "+s"(br.buf), [cnt] "+s"(br.cnt)
-                        : [onward] "v"(onward), [mine] "v"(mine), [K1] "s"(K1), [outlen] "s"(out_len), [dst] "s"(dst)
-                        : "scc", "vcc", "memory");
-                    if (e) break;
+                if (!have) {
+                    for (;;) {  // a run of literals
+                        window_walk(br, S.lit, lane, w);
+                        window_emit(br, w, dst, pos, out_len);
+                        if (w.e) break;
+                    }
                 }
+                have = false;
+                uint32_t e = w.e;
                 br.refill();  // the window may have left as few as 15 bits: the code below and its extra bits take up to 20
                 uint32_t cl = e & 15u;
                 if (cl == 0) {  // a code longer than the primary table's bits (or no code at all)
@@ -524,42 +553,42 @@ __device__ uint32_t inflate_member(const uint32_t* __restrict__ file32, uint64_t
                 const uint32_t dist = (((d >> 8) & 3u) << dxb) + 1u + br.bits(dxb);
                 if (dist > pos) INF_FAIL(INF_ERR_DIST);
                 if (pos + len > out_len) INF_FAIL(INF_ERR_OUTPUT);
-                // The copy.  Alone in its SIMD a wave spends most of its time here, a memory round trip per match between
-                // the load of the source bytes and their store; so a match of up to 64 bytes (nearly all are) only loads,
-                // and its store waits until the next match (or the member's end) -- the window and the codes in between
-                // are decoded while the bytes are on their way.  The pending store goes out before the next load, whose
-                // source it may be: a wave's vector memory operations are performed in order.
-                if (pend) dst[pend_at] = (uint8_t)pend_byte;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, INF_FENCE_SCOPE);  // the copy reads what this wave has stored
+                // The copy: the wave reads what it has stored, and a wave's vector memory operations are performed in order.
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, INF_FENCE_SCOPE);
                 const uint8_t* src = dst + (pos - dist);
                 // No branch on the lane anywhere (the lanes beyond the match repeat its last byte): with any divergent
                 // branch in the symbol loop the compiler structurizes the whole loop and joins its paths through flag
                 // registers, a dozen scalar moves per match.
                 const uint32_t last = len - 1u;
-                pend = len <= 64;
-                if (pend) {
+                if (len <= 64) {
                     uint32_t i = min((uint32_t)lane, last);
-                    pend_at = pos + i;
+                    const uint32_t at = pos + i;
                     if (dist < len) i %= dist;  // the match overlaps itself: its bytes repeat with period dist, all of them already written
-                    pend_byte = src[i];
-                } else if (dist >= len) {
-                    for (uint32_t b0 = 0; b0 < len; b0 += 64) {
-                        const uint32_t i = min(b0 + (uint32_t)lane, last);
-                        dst[pos + i] = src[i];
-                    }
+                    const uint8_t byte = src[i];
+                    pos += len;
+                    window_walk(br, S.lit, lane, w);
+                    dst[at] = byte;
+                    window_emit(br, w, dst, pos, out_len);
+                    have = w.e != 0;
                 } else {
-                    for (uint32_t b0 = 0; b0 < len; b0 += 64) {
-                        const uint32_t i = min(b0 + (uint32_t)lane, last);
-                        dst[pos + i] = src[i % dist];
+                    if (dist >= len) {
+                        for (uint32_t b0 = 0; b0 < len; b0 += 64) {
+                            const uint32_t i = min(b0 + (uint32_t)lane, last);
+                            dst[pos + i] = src[i];
+                        }
+                    } else {
+                        for (uint32_t b0 = 0; b0 < len; b0 += 64) {
+                            const uint32_t i = min(b0 + (uint32_t)lane, last);
+                            dst[pos + i] = src[i % dist];
+                        }
                     }
+                    pos += len;
                 }
-                pos += len;
             }
             if (br.bit_pos() > end_bit) INF_FAIL(INF_ERR_INPUT);  // checked per block: its symbols are bounded by ISIZE either way
         }
         if (bfinal) break;
     }
-    if (pend) dst[pend_at] = (uint8_t)pend_byte;
     if (pos != out_len) INF_FAIL(INF_ERR_SHORT);
     return INF_OK;
 }
