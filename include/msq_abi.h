@@ -552,6 +552,9 @@ int msq_bam_index_device(msq_ctx* ctx, msq_bam_dev* bam, uint64_t first_record_o
                          int32_t region_end0, uint64_t* n_records, uint64_t* n_kept);
 /* the kept records' table, and their names back to back (l_read_name bytes each, NUL included), to the host */
 int msq_bam_records(msq_ctx* ctx, const msq_bam_dev* bam, msq_bam_record* host_kept /* [n_kept] */);
+/* ... or the library's own host copy of that table, [n_kept], valid until msq_bam_dev_free or the next
+ * msq_bam_index_device on `bam` (NULL before the index, or when nothing was kept): no second copy of 72 bytes a record */
+const msq_bam_record* msq_bam_records_view(const msq_bam_dev* bam);
 int msq_bam_names(msq_ctx* ctx, const msq_bam_dev* bam, char* host_buf, uint64_t buf_bytes);
 /* Kept records [first, first + count) decoded and packed on the device: the same packed set, bit for bit, as
  * msq_pack_reads_device_fill_compact fed by the host front's decoder (thresholds applied while decoding; pack_flags as

@@ -168,6 +168,7 @@ _SIGNATURES = {
     "msq_bam_dev_free": (C.c_int, [_P, _P]),
     "msq_bam_index_device": (C.c_int, [_P, _P, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "msq_bam_records": (C.c_int, [_P, _P, _P]),
+    "msq_bam_records_view": (C.c_void_p, [_P]),
     "msq_bam_names": (C.c_int, [_P, _P, _P, C.c_uint64]),
     "msq_bam_pack_device": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(QvThresholds), C.POINTER(_P)]),
     "msq_debug_merged_launches": (C.c_int, []),

@@ -641,10 +641,9 @@ struct BamUtils
             Msq::Check(rc);
         }
         const auto t4 = Clock::now();
-        std::vector<msq_bam_record> kept(nKept);
-        Msq::Check(msq_bam_records(ctx, dev->bam, kept.data()));
+        const msq_bam_record* const kept = msq_bam_records_view(dev->bam);  // the library's table: no copy of 72 bytes a record
         uint64_t nameBytes = 0;
-        for (const auto& k : kept) nameBytes += k.l_read_name;
+        for (size_t r = 0; r < nKept; ++r) nameBytes += kept[r].l_read_name;
         std::vector<char> nameBuf(nameBytes + 1);
         Msq::Check(msq_bam_names(ctx, dev->bam, nameBuf.data(), nameBytes));
         const auto t5 = Clock::now();

@@ -527,12 +527,20 @@ extern "C" int msq_bam_records(msq_ctx* ctx, const msq_bam_dev* bam, msq_bam_rec
     return MSQ_OK;
 }
 
+extern "C" const msq_bam_record* msq_bam_records_view(const msq_bam_dev* bam)
+{
+    return bam && !bam->h_kept.empty() ? bam->h_kept.data() : nullptr;
+}
+
 extern "C" int msq_bam_names(msq_ctx* ctx, const msq_bam_dev* bam, char* host_buf, uint64_t buf_bytes)
 {
     if (!ctx || !bam) return msq_fail(MSQ_ERR_ARG, "msq_bam_names: NULL argument");
     const uint64_t n = bam->n_kept;
     if (n == 0) return MSQ_OK;
     MSQ_HIP(hipSetDevice(ctx->device));
+    const bool trace = getenv("MSQ_BAM_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&t0]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
     std::vector<uint64_t> off;
     try {
         off.resize(n + 1);
@@ -542,19 +550,22 @@ extern "C" int msq_bam_names(msq_ctx* ctx, const msq_bam_dev* bam, char* host_bu
     off[0] = 0;
     for (uint64_t r = 0; r < n; ++r) off[r + 1] = off[r] + bam->h_kept[r].l_read_name;
     if (!host_buf || buf_bytes < off[n]) return msq_fail(MSQ_ERR_ARG, "msq_bam_names: the buffer holds %llu bytes, the names take %llu", (unsigned long long)buf_bytes, (unsigned long long)off[n]);
-    void *d_off = nullptr, *d_names = nullptr;
-    hipError_t e = hipMalloc(&d_off, (n + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc(&d_names, std::max<uint64_t>(off[n], 4));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    // offsets and names in the context's scratch (free between the inflate, whose file image it held, and the pack)
+    const uint64_t off_bytes = ((n + 1) * 8 + 255) & ~255ull;
+    void* scratch = nullptr;
+    if (int rc = msq_scratch(ctx, off_bytes + std::max<uint64_t>(off[n], 4), &scratch)) return rc;
+    void* const d_off = scratch;
+    void* const d_names = (char*)scratch + off_bytes;
+    const double t_off = ms_since();
+    hipError_t e = hipMemcpyAsync(d_off, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(bam_names_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, ctx->stream, bam->d_data, bam->d_kept, n, (const uint64_t*)d_off, (char*)d_names);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(host_buf, d_names, off[n], hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (d_off) (void)hipFree(d_off);
-    if (d_names) (void)hipFree(d_names);
     if (e != hipSuccess) return msq_fail(e == hipErrorOutOfMemory ? MSQ_ERR_NOMEM : MSQ_ERR_HIP, "msq_bam_names: %s", hipGetErrorString(e));
+    if (trace) std::fprintf(stderr, "msq_bam_names: %llu names, %.1f MB: offsets at %.2f ms, done at %.2f ms\n", (unsigned long long)n, off[n] / 1e6, t_off, ms_since());
     return MSQ_OK;
 }
 

@@ -63,6 +63,11 @@ class DevBam:
         abi.check(self.L.msq_bam_index_device(self.ctx.h, self.h, self.first, self.n_ref, lo, hi, C.byref(n_rec), C.byref(n_kept)))
         recs = (abi.BamRecord * max(n_kept.value, 1))()
         abi.check(self.L.msq_bam_records(self.ctx.h, self.h, C.cast(recs, C.c_void_p)))
+        view = self.L.msq_bam_records_view(self.h)  # the library's own copy of the table: the same bytes
+        if n_kept.value:
+            assert C.string_at(view, n_kept.value * C.sizeof(abi.BamRecord)) == bytes(recs)[:n_kept.value * C.sizeof(abi.BamRecord)]
+        else:
+            assert not view
         total = sum(recs[i].l_read_name for i in range(n_kept.value))
         buf = C.create_string_buffer(max(total, 1))
         abi.check(self.L.msq_bam_names(self.ctx.h, self.h, buf, total))
