@@ -291,6 +291,18 @@ struct CompactRows {  // per cigar op "MIDNSHP=X": the byte of each SEQ code "=A
     uint8_t gap[9];
 };
 
+struct RunTable {  // a chunk of <= 64 cigar runs of one record (a wave's own): output offset within the chunk, first query base, op (0xff: writes nothing)
+    uint32_t o_rel[64], q_at[64];
+    uint8_t op[64];
+};
+
+// one wave owns its RunTable and the LDS performs a wave's operations in order: the compiler must keep them in order too
+__device__ inline void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // DecodeBasesCompact, a wave per kept record
 __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restrict__ d, const msq_bam_record* __restrict__ kept, uint64_t n_reads,
                                                          const uint64_t* __restrict__ base_off, int32_t region_start, int32_t region_end,
@@ -298,11 +310,13 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
                                                          uint32_t* __restrict__ presence)
 {
     __shared__ CompactRows rows;
+    __shared__ RunTable runs[4];
     for (uint32_t i = threadIdx.x; i < sizeof(CompactRows); i += 256) reinterpret_cast<uint8_t*>(&rows)[i] = reinterpret_cast<const uint8_t*>(&rows_arg)[i];
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63u);
     const uint64_t r = (uint64_t)blockIdx.x * 4 + uni(threadIdx.x >> 6);
     if (r >= n_reads) return;
+    RunTable& my = runs[uni(threadIdx.x >> 6)];
     const msq_bam_record k = kept[r];
     const uint8_t* rec = d + k.body_off;
     const uint32_t n_cigar = k.n_cigar;
@@ -340,44 +354,60 @@ __global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restri
         }
         const int64_t oi = wave_incl_scan(cnt, lane);
         const int64_t o_at = out0 + oi - cnt, q_at = qp + skip;
-        const uint32_t n_here = min(64u, n_cigar - c0);
-        for (uint32_t j = 0; j < n_here; ++j) {
-            const int64_t cnt_j = __shfl(cnt, (int)j, 64);
-            if (cnt_j == 0) continue;
-            const uint32_t op_j = (uint32_t)__shfl((int)op, (int)j, 64);
-            const int64_t o_j = __shfl(o_at, (int)j, 64), q_j = __shfl(q_at, (int)j, 64);
-            if (o_j + cnt_j > room) continue;  // cannot happen: n_bases is this same arithmetic
-            if (op_cons_query(op_j)) {
-                if (q_j + cnt_j > (int64_t)l_seq) continue;  // "CIGAR longer than SEQ": such a record is never packed
-                for (int64_t t = lane; t < cnt_j; t += 64) {
-                    const uint64_t q = (uint64_t)(q_j + t);
-                    const uint32_t nib = (seq[q >> 1] >> ((q & 1) ? 0 : 4)) & 15u;
-                    uint8_t c = rows.seq[op_j][nib];
-                    if (c & 0x80) c = 12;  // a cigar the MSA throws on: flagged by the record pass, never packed
-                    if (any_thr) {
-                        // ArrayBase::MeetQVThresholds (ArrayRead.inl:67-87): every base carries a QualQV (0 without QUAL,
-                        // ArrayRead.cpp:94-96), the rich QVs when all three tags are there (native orientation)
-                        bool fail = (int)(has_qual ? qual[q] : (uint8_t)0) < thr.qual;
-                        if (rich) {
-                            const uint64_t i = reverse ? l_seq - 1 - q : q;
-                            fail = fail || (int)(uint8_t)(dq[i] - 33) < thr.del || (int)(uint8_t)(sq[i] - 33) < thr.sub || (int)(uint8_t)(iq[i] - 33) < thr.ins;
-                        }
-                        if (fail) c = MSQ_COMPACT_FAIL(c);
-                    }
-                    dst[o_j + t] = c;
+        // The chunk's runs laid out for a flat walk over its OUTPUT bases: a read has ~50 runs of ~60 bases, and a loop
+        // over the runs is a chain of ~50 memory round trips (load the run's bases, then store them); with the runs'
+        // output offsets in LDS every lane finds the run of its output base by bisection, and the bases of all runs are
+        // loaded side by side.  A run that would not fit (cannot happen: n_bases is this same arithmetic) or that reaches
+        // beyond SEQ ("CIGAR longer than SEQ": such a record is never packed) writes nothing, as before.
+        const bool fits = o_at + cnt <= room && (!cq || q_at + cnt <= (int64_t)l_seq);
+        const int64_t total_here = __shfl(oi, 63, 64);
+        wave_lds_sync();  // the previous chunk's readers are done
+        my.o_rel[lane] = (uint32_t)(o_at - out0);
+        my.q_at[lane] = (uint32_t)q_at;
+        my.op[lane] = (uint8_t)((cnt > 0 && fits) ? op : 0xffu);
+        wave_lds_sync();
+#ifndef MSQ_DECODE_UNROLL
+#define MSQ_DECODE_UNROLL 4
+#endif
+#pragma unroll MSQ_DECODE_UNROLL
+        for (int64_t p = lane; p < total_here; p += 64) {
+            // the last run that starts at or before p (runs without output share their successor's offset)
+            uint32_t j = 0;
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1)
+                if (my.o_rel[j + step] <= (uint32_t)p) j += step;
+            // no branch on the lane up to the store: the loads of the unrolled passes can then be in flight together
+            const uint32_t op_raw = my.op[j];
+            const bool live = op_raw != 0xffu;
+            const uint32_t op_j = live ? op_raw : 0u;
+            const bool from_seq = live && op_cons_query(op_j);
+            const uint64_t q = from_seq ? (uint64_t)my.q_at[j] + ((uint64_t)p - my.o_rel[j]) : 0ull;  // a base of SEQ, or SEQ's first byte for nothing
+            const uint32_t nib = (seq[q >> 1] >> ((q & 1) ? 0 : 4)) & 15u;
+            uint8_t c = from_seq ? rows.seq[op_j][nib] : rows.gap[op_j];
+            if (c & 0x80) c = 12;  // a cigar the MSA throws on: flagged by the record pass, never packed
+            if (any_thr) {
+                // ArrayBase::MeetQVThresholds (ArrayRead.inl:67-87): every base carries a QualQV (0 without QUAL,
+                // ArrayRead.cpp:94-96), the rich QVs when all three tags are there (native orientation); a placeholder
+                // base has QualQV 0 and rich QVs 0
+                bool fail = (int)(has_qual ? qual[q] : (uint8_t)0) < thr.qual;
+                if (rich) {
+                    const uint64_t i = reverse ? l_seq - 1 - q : q;
+                    fail = fail || (int)(uint8_t)(dq[i] - 33) < thr.del || (int)(uint8_t)(sq[i] - 33) < thr.sub || (int)(uint8_t)(iq[i] - 33) < thr.ins;
                 }
-            } else {
-                uint8_t c = rows.gap[op_j];
-                if (c & 0x80) c = 12;
-                if (gap_fails) c = MSQ_COMPACT_FAIL(c);
-                for (int64_t t = lane; t < cnt_j; t += 64) dst[o_j + t] = c;
+                if (from_seq ? fail : gap_fails) c = MSQ_COMPACT_FAIL(c);
             }
+            if (live) dst[out0 + p] = c;
         }
         rp0 += __shfl(ri, 63, 64);
         qp0 += __shfl(qi, 63, 64);
         out0 += __shfl(oi, 63, 64);
     }
-    if (lane == 0 && room > 0) atomicOr(presence, 1u | (rich ? 2u : 0u));
+    // 10^5 waves OR into one word (same-address atomics pass the L2 one by one): the bits are only ever set, so a wave
+    // that reads them set has nothing to add
+    if (lane == 0 && room > 0) {
+        const uint32_t want = 1u | (rich ? 2u : 0u);
+        if ((__hip_atomic_load(presence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & want) != want) atomicOr(presence, want);
+    }
 }
 
 }  // namespace
@@ -621,6 +651,7 @@ extern "C" int msq_bam_pack_device(msq_ctx* ctx, const msq_bam_dev* bam, uint64_
     if (e == hipSuccess) e = hipMemsetAsync(d_presence, 0, 4, ctx->stream);
     uint32_t presence = 0;
     if (e == hipSuccess && count) {
+        // (a wave per read: waves that stride over the reads, eight workgroups per CU, took 1.33 instead of 0.86 ms)
         hipLaunchKernelGGL(bam_decode_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, ctx->stream, bam->d_data, bam->d_kept + first, count,
                            (const uint64_t*)d_base_off, bam->region_start0, bam->region_end0, thr, rows, (uint8_t*)d_compact, (uint32_t*)d_presence);
         e = hipGetLastError();

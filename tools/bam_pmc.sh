@@ -14,5 +14,5 @@ for PASS in \
   i=$((i+1))
   MSQ_BAM_PIECES=1 timeout -s KILL 120 rocprofv3 --pmc $PASS --output-format csv -d "$ROOT/$OUT/pass$i" -o pmc -- "$ROOT/tests/cpp/bam_test" /tmp/bench.bam 0 2147483647 --device --threads 16 > "$ROOT/$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$ROOT/$OUT/pass$i.log"; exit 1; }
   f=$(find "$ROOT/$OUT/pass$i" -name "*counter_collection.csv" | head -1)
-  python3 "$ROOT/tools/pmc_summary.py" "$f" bgzf_inflate
+  python3 "$ROOT/tools/pmc_summary.py" "$f" ${KERNEL:-bgzf_inflate}
 done
