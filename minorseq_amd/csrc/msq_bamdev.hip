@@ -304,17 +304,21 @@ __device__ inline void wave_lds_sync()
 }
 
 // DecodeBasesCompact, a wave per kept record
-__global__ __launch_bounds__(256) void bam_decode_kernel(const uint8_t* __restrict__ d, const msq_bam_record* __restrict__ kept, uint64_t n_reads,
+#ifndef MSQ_DECODE_WAVES
+#define MSQ_DECODE_WAVES 4
+#endif
+constexpr int kDecodeWaves = MSQ_DECODE_WAVES;  // reads (waves) per workgroup
+__global__ __launch_bounds__(64 * kDecodeWaves) void bam_decode_kernel(const uint8_t* __restrict__ d, const msq_bam_record* __restrict__ kept, uint64_t n_reads,
                                                          const uint64_t* __restrict__ base_off, int32_t region_start, int32_t region_end,
                                                          msq_qv_thresholds thr, CompactRows rows_arg, uint8_t* __restrict__ dst_all,
                                                          uint32_t* __restrict__ presence)
 {
     __shared__ CompactRows rows;
-    __shared__ RunTable runs[4];
-    for (uint32_t i = threadIdx.x; i < sizeof(CompactRows); i += 256) reinterpret_cast<uint8_t*>(&rows)[i] = reinterpret_cast<const uint8_t*>(&rows_arg)[i];
+    __shared__ RunTable runs[kDecodeWaves];
+    for (uint32_t i = threadIdx.x; i < sizeof(CompactRows); i += 64 * kDecodeWaves) reinterpret_cast<uint8_t*>(&rows)[i] = reinterpret_cast<const uint8_t*>(&rows_arg)[i];
     __syncthreads();
     const int lane = (int)(threadIdx.x & 63u);
-    const uint64_t r = (uint64_t)blockIdx.x * 4 + uni(threadIdx.x >> 6);
+    const uint64_t r = (uint64_t)blockIdx.x * kDecodeWaves + uni(threadIdx.x >> 6);
     if (r >= n_reads) return;
     RunTable& my = runs[uni(threadIdx.x >> 6)];
     const msq_bam_record k = kept[r];
@@ -652,7 +656,7 @@ extern "C" int msq_bam_pack_device(msq_ctx* ctx, const msq_bam_dev* bam, uint64_
     uint32_t presence = 0;
     if (e == hipSuccess && count) {
         // (a wave per read: waves that stride over the reads, eight workgroups per CU, took 1.33 instead of 0.86 ms)
-        hipLaunchKernelGGL(bam_decode_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, ctx->stream, bam->d_data, bam->d_kept + first, count,
+        hipLaunchKernelGGL(bam_decode_kernel, dim3((unsigned)((count + kDecodeWaves - 1) / kDecodeWaves)), dim3(64 * kDecodeWaves), 0, ctx->stream, bam->d_data, bam->d_kept + first, count,
                            (const uint64_t*)d_base_off, bam->region_start0, bam->region_end0, thr, rows, (uint8_t*)d_compact, (uint32_t*)d_presence);
         e = hipGetLastError();
     }
