@@ -575,7 +575,7 @@ int msq_debug_phase_lookups(void);
 #define MSQ_TUNE_NO_MERGE 1
 #define MSQ_TUNE_CARRIER_MIN_BATCHES 2
 #define MSQ_TUNE_NO_HAPS 3 /* msq_reads_align makes no haplotype groups (MSQ_NO_HAPS in the environment) */
-#define MSQ_TUNE_BAM_PIECES 5 /* msq_bgzf_inflate_device: pieces a large file crosses PCIe in, each inflated behind its copy (default 2) */
+#define MSQ_TUNE_BAM_PIECES 5 /* msq_bgzf_inflate_device: pieces a large file crosses PCIe in, each inflated behind its copy (default 3) */
 #define MSQ_TUNE_BAM_PIECE_MIN_BYTES 6 /* ... and from which file size on (default 32 MB; tests set 0) */
 #define MSQ_TUNE_BAM_SEGMENT 4 /* msq_bam_index_device: bytes per segment of the record-start search (default 16384, >= 64) */
 int msq_debug_tune(msq_ctx* ctx, int key, long long value);

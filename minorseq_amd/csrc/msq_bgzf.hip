@@ -643,10 +643,11 @@ void msq_bgzf_drop_staged(msq_ctx* ctx)
 // The file image on its way into the context's scratch: pieces on the copy stream, an event behind each.  The copies are
 // fed by threads of the library's own and this call returns at once: the caller scans the BGZF headers meanwhile, and
 // msq_bgzf_inflate_device launches every piece's kernel behind that piece's event (it stages the image itself when
-// nobody has).  Two pieces, 40 % and 60 %: a kernel takes ~5.5 ms however few members it has (one member is one wave,
-// ~8000 dependent windows and 6400 matches with a memory round trip each) and 1.4 us per member once the chip's issue
-// slots are full (10^5 reads: 9.7 ms), so more pieces cost more than they hide (tools/bam_share_ab.sh); the pieces'
-// kernels run side by side on two streams (tools/bam_timeline.sh).
+// nobody has).  Three pieces (4 : 3 : 2): a kernel takes ~5 ms however few members it has (one member is one wave,
+// ~8000 dependent windows and 6400 matches with a memory round trip each) and 1.3 us per member once the chip's issue
+// slots are full (10^5 reads: 9.2 ms), so a piece's kernel should be running while the next piece arrives; the pieces'
+// kernels run side by side on three streams (tools/bam_timeline.sh; tools/bam_share_ab.sh: two to four pieces are
+// within 0.5 ms of each other, one piece is 2 ms behind).
 extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t file_bytes)
 {
     if (!ctx || (file_bytes && !file)) return msq_fail(MSQ_ERR_ARG, "msq_bgzf_stage_file: NULL argument");
@@ -817,7 +818,8 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
     if (!was_staged)
         if (int rc = msq_bgzf_stage_file(ctx, file, file_bytes)) return rc;
     if (!ctx->copy_stream) MSQ_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    if (!ctx->side_stream) MSQ_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    for (hipStream_t& st : ctx->side_stream)
+        if (!st) MSQ_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (hipEvent_t& ev : ctx->side_event)
         if (!ev) MSQ_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const double t_staged = ms_since();
@@ -827,7 +829,7 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
         return msq_fail(MSQ_ERR_NOMEM, "msq_bgzf_inflate_device: out of memory");
     }
     auto fail = [&](int code, const char* what, hipError_t e) {
-        (void)hipStreamSynchronize(ctx->side_stream);
+        for (hipStream_t st : ctx->side_stream) (void)hipStreamSynchronize(st);
         (void)hipStreamSynchronize(ctx->stream);
         msq_bgzf_drop_staged(ctx);
         free_bam_dev(b);
@@ -863,11 +865,12 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
     e = hipMemsetAsync(b->d_data + total, 0, MSQ_BAM_DATA_PAD, ctx->stream);
     if (e == hipSuccess && n_members) e = hipMemcpyAsync(d_members, members, n_members * sizeof(msq_bgzf_member), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_status, 0xFF, status_bytes, ctx->stream);
-    // every piece's members behind its copy, the pieces' kernels in turn on the context's stream and on the side stream.
+    // every piece's members behind its copy, the pieces' kernels in turn on the context's stream and the two side streams.
     // (A wave may look up to two chunks past its member into bytes that have not arrived: bits no valid stream consumes.)
     if (e == hipSuccess) e = hipEventRecord(ctx->side_event[0], ctx->stream);  // the tables are in place
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->side_stream, ctx->side_event[0], 0);
-    bool side_used = false;
+    for (hipStream_t st : ctx->side_stream)
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->side_event[0], 0);
+    bool side_used[2] = {false, false};
     uint64_t m0 = 0;
     for (int k = 0; e == hipSuccess && k < ctx->staged_total; ++k) {
         const bool last = k + 1 == ctx->staged_total;
@@ -881,18 +884,20 @@ extern "C" int msq_bgzf_inflate_device(msq_ctx* ctx, const uint8_t* file, uint64
             e = (hipError_t)ctx->staged_err.load();
             break;
         }
-        hipStream_t on = (k & 1) ? ctx->side_stream : ctx->stream;
+        hipStream_t on = k % 3 ? ctx->side_stream[k % 3 - 1] : ctx->stream;
         e = hipStreamWaitEvent(on, ctx->staged_event[k], 0);
         if (e == hipSuccess && m1 > m0) {
-            side_used |= (k & 1) != 0;
+            if (k % 3) side_used[k % 3 - 1] = true;
             hipLaunchKernelGGL(bgzf_inflate_kernel, dim3((unsigned)((m1 - m0 + 3) / 4)), dim3(256), 0, on, (const uint32_t*)d_file, file_padded / 4,
                                (const msq_bgzf_member*)d_members + m0, (uint32_t)(m1 - m0), b->d_data, (uint32_t*)d_status + m0);
             e = hipGetLastError();
         }
         m0 = m1;
     }
-    if (e == hipSuccess && side_used) e = hipEventRecord(ctx->side_event[1], ctx->side_stream);
-    if (e == hipSuccess && side_used) e = hipStreamWaitEvent(ctx->stream, ctx->side_event[1], 0);
+    for (int i = 0; i < 2; ++i) {
+        if (e == hipSuccess && side_used[i]) e = hipEventRecord(ctx->side_event[1 + i], ctx->side_stream[i]);
+        if (e == hipSuccess && side_used[i]) e = hipStreamWaitEvent(ctx->stream, ctx->side_event[1 + i], 0);
+    }
     const double t_issued = ms_since();
     if (e == hipSuccess && n_members) e = hipMemcpyAsync(status.data(), d_status, n_members * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -128,7 +128,8 @@ extern "C" int msq_ctx_destroy(msq_ctx* ctx)
     if (ctx->d_bam_tables) (void)hipFree(ctx->d_bam_tables);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->pinned_ring) (void)hipHostFree(ctx->pinned_ring);
-    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    for (hipStream_t st : ctx->side_stream)
+        if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t ev : ctx->side_event)
         if (ev) (void)hipEventDestroy(ev);
     timing_release(ctx);

@@ -63,14 +63,14 @@ struct msq_ctx {
     bool no_haps = false;              // MSQ_NO_HAPS / MSQ_TUNE_NO_HAPS: msq_reads_align makes no haplotype groups
     // msq_bgzf_inflate_device: the file image's pieces cross PCIe on copy_stream beside the inflate kernels of the pieces before
     hipStream_t copy_stream = nullptr;
-    // ... and every second piece's kernel on side_stream: a piece's kernel takes as long as one wave needs for one member
-    // however few its members, so the pieces' kernels overlap instead of queueing (side_event: the two streams' joins)
+    // ... and the pieces' kernels in turn on the context's stream and the two side streams: a piece's kernel takes as long
+    // as one wave needs for one member however few its members, so the pieces' kernels overlap instead of queueing
     // msq_bgzf_stage_file: the ring of pinned slots the copy threads fill from the file's mapping (kept for the context's life)
     void* pinned_ring = nullptr;
     uint64_t pinned_ring_bytes = 0;
     uint64_t bam_upload_threads = 4;     // 0: one hipMemcpyAsync per piece straight from the pageable mapping
-    hipStream_t side_stream = nullptr;
-    hipEvent_t side_event[2] = {nullptr, nullptr};
+    hipStream_t side_stream[2] = {nullptr, nullptr};
+    hipEvent_t side_event[3] = {nullptr, nullptr, nullptr};  // the tables are in place; side stream 0 / 1 has done its kernels
     // msq_bgzf_stage_file: the file image now in the scratch (host pointer and size as its name), the pieces' ends and events
     const uint8_t* staged_file = nullptr;
     uint64_t staged_bytes = 0, staged_upto[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -80,7 +80,7 @@ struct msq_ctx {
     std::thread* stage_thread = nullptr; // issues the copies (a pageable copy blocks its thread)
     void* d_bam_tables = nullptr;        // msq_bgzf_inflate_device: member table + status words
     size_t bam_tables_bytes = 0;
-    uint64_t bam_pieces = 2;             // msq_bgzf_inflate_device: pieces a file of >= bam_piece_min_bytes is uploaded and inflated in
+    uint64_t bam_pieces = 3;             // msq_bgzf_inflate_device: pieces a file of >= bam_piece_min_bytes is uploaded and inflated in
     uint64_t bam_piece_min_bytes = (uint64_t)32 << 20;
     uint64_t bam_first_share_pct = 40;   // two pieces: the first one's share of the file
     uint64_t bam_segment_bytes = 16384;  // msq_bam_index_device: the stream is searched for record starts in segments of this size

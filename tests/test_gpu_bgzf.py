@@ -133,7 +133,7 @@ def test_many_members_and_odd_payload_offsets(ctx):
             assert inflate_device(ctx, blob, members) == want
     finally:
         L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECE_MIN_BYTES, 32 << 20)
-        L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, 2)
+        L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, 3)
 
 
 def test_large_image_crosses_in_ring_slots(ctx):
@@ -159,7 +159,7 @@ def test_large_image_crosses_in_ring_slots(ctx):
             assert len(got) == len(want)
             assert got == want, pieces
     finally:
-        L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, 2)
+        L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, 3)
 
 
 def test_bam_shaped_members(ctx, tmp_path):
