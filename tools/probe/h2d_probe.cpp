@@ -1,6 +1,6 @@
 // How fast does a mapped file reach the GPU?  (a) hipMemcpyAsync from the pageable mapping (what msq_bgzf_stage_file does),
-// run on the GPU box: hipcc -O2 -pthread --offload-arch=gfx950 tools/probe/h2d_probe.cpp -o tools/probe/h2d_probe && tools/probe/h2d_probe file [threads] [slot MB] [slots]
-// (b) T threads copy slices of the mapping into pinned slots, each slot then crosses by DMA.  Build: hipcc -O2 -pthread.
+// (b) T threads copy slices of the mapping into pinned slots, each slot then crosses by DMA.
+// Build here, run on the GPU box: hipcc -O2 -pthread --offload-arch=gfx950 tools/probe/h2d_probe.cpp -o tools/probe/h2d_probe && tools/probe/h2d_probe file [threads] [slot MB] [slots]
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <sys/mman.h>
