@@ -331,6 +331,8 @@ __global__ __launch_bounds__(64 * kDecodeWaves) void bam_decode_kernel(const uin
     const bool has_qual = k.has_qual != 0, rich = k.sq_off != 0, reverse = (k.flag & 0x10u) != 0;
     const uint8_t *sq = rec + k.sq_off, *dq = rec + k.dq_off, *iq = rec + k.iq_off;
     const bool any_thr = thr.qual >= 0 || thr.del >= 0 || thr.sub >= 0 || thr.ins >= 0;
+    const bool need_qual = has_qual && thr.qual > 0, need_del = thr.del > 0, need_sub = thr.sub > 0, need_ins = thr.ins > 0;
+    const bool no_qual_fails = !has_qual && 0 < thr.qual;  // without QUAL every base carries QualQV 0
     // a placeholder base ('-' / '*', QualQV 0, rich QVs 0) misses a threshold above 0
     const bool gap_fails = any_thr && (0 < thr.qual || (rich && (0 < thr.del || 0 < thr.sub || 0 < thr.ins)));
     const int64_t ref_start = k.ref_start, ref_end = k.ref_end;
@@ -393,10 +395,14 @@ __global__ __launch_bounds__(64 * kDecodeWaves) void bam_decode_kernel(const uin
                 // ArrayBase::MeetQVThresholds (ArrayRead.inl:67-87): every base carries a QualQV (0 without QUAL,
                 // ArrayRead.cpp:94-96), the rich QVs when all three tags are there (native orientation); a placeholder
                 // base has QualQV 0 and rich QVs 0
-                bool fail = (int)(has_qual ? qual[q] : (uint8_t)0) < thr.qual;
+                // (a byte is never below a threshold of 0 or less: such a string is not read -- with the reference's defaults,
+                // SUBQV 42 and the others unset, that is QUAL and two of the three tags, two thirds of the kernel's loads)
+                bool fail = no_qual_fails || (need_qual && (int)qual[q] < thr.qual);
                 if (rich) {
                     const uint64_t i = reverse ? l_seq - 1 - q : q;
-                    fail = fail || (int)(uint8_t)(dq[i] - 33) < thr.del || (int)(uint8_t)(sq[i] - 33) < thr.sub || (int)(uint8_t)(iq[i] - 33) < thr.ins;
+                    if (need_del) fail = fail || (int)(uint8_t)(dq[i] - 33) < thr.del;
+                    if (need_sub) fail = fail || (int)(uint8_t)(sq[i] - 33) < thr.sub;
+                    if (need_ins) fail = fail || (int)(uint8_t)(iq[i] - 33) < thr.ins;
                 }
                 if (from_seq ? fail : gap_fails) c = MSQ_COMPACT_FAIL(c);
             }
