@@ -290,37 +290,26 @@ __global__ __launch_bounds__((MANY_N ? kRowsWavesN : kRowsWaves) * 64) void pile
             const int ov = W - cbase;
             const uint32_t inw = ov >= 32 ? 0xffffffffu : ov <= 0 ? 0u : ((1u << ov) - 1u);
             const uint32_t nd = lo.x & ~m_lo & inw, cd = cv & ~cm, nn = COUNT_N ? 0u : (lo.y & lo.z & inw);
-            // what matches the set's alt haplotype -- a minor variant carried by a share of the reads -- is counted in
-            // LDS (the sum leaves with the workgroup's partial); only what matches neither pays a global atomic
-            const uint4 al = *reinterpret_cast<const uint4*>(gl2 + cgq * 4), ah = *reinterpret_cast<const uint4*>(gl2 + cgq * 4 + 4);
-            const uint32_t am_lo = lo.x & al.x & ~((lo.z ^ al.y) | (lo.w ^ al.z));
-            const uint32_t am_hi = hv & ah.x & ~((hb0 ^ ah.y) | (hb1 ^ ah.z));
-            const uint32_t nd_alt = nd & am_lo;
-            const uint32_t cd_alt = cd & am_lo & funnel(am_lo, am_hi, 1) & funnel(am_lo, am_hi, 2);
-            uint32_t bits = nd_alt | cd_alt;
-            while (bits) {
-                const int j = __ffs(bits) - 1;
-                bits &= bits - 1;
-                __hip_atomic_fetch_add(&altc[lbase + j], ((nd_alt >> j) & 1u) | (((cd_alt >> j) & 1u) << 16), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                ROWS_DBG(4, 1);
-            }
             // An ISOLATED substitution -- a base that differs from the guide's while the two columns on either side of
             // it match the guide (what a sequencing error looks like) -- changes exactly one
             // nucleotide bin and the three codons that hold it, each in one position: it is counted ONCE, in LDS, by its
             // column and the rank of the base read, and the fold turns the sums into the four bins.  Returnless global
             // atomics run at ~26e9 / s on the whole chip; at the reference's error rate (0.05 %) the four atomics per
             // substitution were a third of the kernel's time, and uniform noise of 2 % cost 20 x a clean sample.
-            uint32_t nd_rest = nd & ~nd_alt, cd_rest = cd & ~cd_alt;
+            // Isolated substitutions come FIRST, before the alt haplotype gets its say: on noisy reads the alt that a
+            // group learns carries noise of its own in many columns, a substitution that happened to agree with it
+            // was booked as "alt" -- and its three codons, which agree with the alt only if the alt is clean around
+            // it, went to HBM one atomic each (1 % substitutions: 22 of them per read, two thirds of the kernel's time).
+            uint32_t nd_w = nd, cd_w = cd;
             // match bits of columns -2 .. 35 of the word (bit = column + 2): the neighbours' as the tag brought them
             const uint32_t mh4 = m_hi | (((tag >> 16) & 3u) << 2);
             const uint64_t M = (uint64_t)((tag >> 14) & 3u) | ((uint64_t)m_lo << 2) | ((uint64_t)mh4 << 34);
             // the next word's isolated substitutions in its columns 0 and 1 (its own entry counts them: the same bits, the
             // same test) change this word's codons at columns 30, 31 / 31: the fold adds those as well
-            const uint32_t fdev = hv & ~m_hi & ~am_hi;
-            if ((fdev & 1u) && (m_lo >> 30) == 3u && (mh4 & 6u) == 6u) cd_rest &= ~(3u << 30);
-            if ((fdev & 2u) && (m_lo >> 31) && (mh4 & 0xdu) == 0xdu) cd_rest &= ~(1u << 31);
-            bits = nd_rest;
+            const uint32_t fdev = hv & ~m_hi;
+            if ((fdev & 1u) && (m_lo >> 30) == 3u && (mh4 & 6u) == 6u) cd_w &= ~(3u << 30);
+            if ((fdev & 2u) && (m_lo >> 31) && (mh4 & 0xdu) == 0xdu) cd_w &= ~(1u << 31);
+            uint32_t bits = nd_w;
             while (bits) {
                 const int j = __ffs(bits) - 1;
                 bits &= bits - 1;
@@ -332,10 +321,26 @@ __global__ __launch_bounds__((MANY_N ? kRowsWavesN : kRowsWaves) * 64) void pile
                     __hip_atomic_fetch_add(&subA[lbase + j], 1u << (16u * r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else
                     __hip_atomic_fetch_add(&subB[lbase + j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                nd_rest &= ~(1u << j);
+                nd_w &= ~(1u << j);
                 ROWS_DBG(5, 1);
-                cd_rest &= ~(uint32_t)((7ull << j) >> 2);  // the codons that start at j - 2, j - 1, j (those of this word): the fold adds them where they count
+                cd_w &= ~(uint32_t)((7ull << j) >> 2);  // the codons that start at j - 2, j - 1, j (those of this word): the fold adds them where they count
             }
+            // what is left and matches the set's alt haplotype -- a minor variant carried by a share of the reads -- is
+            // counted in LDS too (the sum leaves with the workgroup's partial); only what matches neither pays a global atomic
+            const uint4 al = *reinterpret_cast<const uint4*>(gl2 + cgq * 4), ah = *reinterpret_cast<const uint4*>(gl2 + cgq * 4 + 4);
+            const uint32_t am_lo = lo.x & al.x & ~((lo.z ^ al.y) | (lo.w ^ al.z));
+            const uint32_t am_hi = hv & ah.x & ~((hb0 ^ ah.y) | (hb1 ^ ah.z));
+            const uint32_t nd_alt = nd_w & am_lo;
+            const uint32_t cd_alt = cd_w & am_lo & funnel(am_lo, am_hi, 1) & funnel(am_lo, am_hi, 2);
+            bits = nd_alt | cd_alt;
+            while (bits) {
+                const int j = __ffs(bits) - 1;
+                bits &= bits - 1;
+                __hip_atomic_fetch_add(&altc[lbase + j], ((nd_alt >> j) & 1u) | (((cd_alt >> j) & 1u) << 16), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                ROWS_DBG(4, 1);
+            }
+            const uint32_t nd_rest = nd_w & ~nd_alt, cd_rest = cd_w & ~cd_alt;
             bits = nd_rest | nn;  // disjoint: nd lies in V, nn in X
             while (bits) {
                 const int j = __ffs(bits) - 1;
