@@ -659,21 +659,19 @@ extern "C" int msq_bam_pack_device(msq_ctx* ctx, const msq_bam_dev* bam, uint64_
     char* const d_compact = d_base_off + off_bytes;
     hipError_t e = hipMemcpyAsync(d_base_off, base_off.data(), (count + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_presence, 0, 4, ctx->stream);
-    uint32_t presence = 0;
     if (e == hipSuccess && count) {
         // (a wave per read: waves that stride over the reads, eight workgroups per CU, took 1.33 instead of 0.86 ms)
         hipLaunchKernelGGL(bam_decode_kernel, dim3((unsigned)((count + kDecodeWaves - 1) / kDecodeWaves)), dim3(64 * kDecodeWaves), 0, ctx->stream, bam->d_data, bam->d_kept + first, count,
                            (const uint64_t*)d_base_off, bam->region_start0, bam->region_end0, thr, rows, (uint8_t*)d_compact, (uint32_t*)d_presence);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&presence, d_presence, 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         (void)hipStreamSynchronize(ctx->stream);
         return msq_fail(MSQ_ERR_HIP, "msq_bam_pack_device: %s", hipGetErrorString(e));
     }
+    // no wait for the decode: the packer makes its tables and allocates the set's buffers beside it
     const int rc = msq_pack_compact_resident(ctx, count, rs.data(), re.data(), base_off.data(), (const uint64_t*)d_base_off, (const uint8_t*)d_compact,
-                                             presence, pack_flags, &thr, out);
+                                             (const uint32_t*)d_presence, pack_flags, &thr, out);
     (void)hipStreamSynchronize(ctx->stream);  // the scratch may go to its next user
     return rc;
 }

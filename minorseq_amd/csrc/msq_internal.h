@@ -123,6 +123,6 @@ int msq_packed_dev_index(msq_ctx* ctx, msq_packed_dev* d);
 // The device packer over bytes that are already in HBM (msq_bam_pack_device): d_compact holds one translated byte per
 // base (msq_pack_reads_device_fill_compact's staging format), read r at base_off[r]; presence as a fill callback reports it.
 int msq_pack_compact_resident(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end, const uint64_t* base_off,
-                              const uint64_t* d_base_off, const uint8_t* d_compact, uint32_t presence, uint32_t pack_flags,
+                              const uint64_t* d_base_off, const uint8_t* d_compact, const uint32_t* d_presence, uint32_t pack_flags,
                               const msq_qv_thresholds* thr, msq_packed_dev** out);
 int msq_validate_reads(const msq_packed_reads* d_reads, const msq_qv_thresholds* thr, const char* who);

@@ -707,9 +707,11 @@ __global__ __launch_bounds__(256) void pack_compact_reads_kernel(const uint8_t* 
 
 // The device packer over translated bytes that are already in HBM (the BAM front on the device, msq_bam_pack_device):
 // the tail of pack_reads_device_impl without staging -- read tables up, one pack_groups_kernel over all groups, flags,
-// column index.  Same packed bytes as msq_pack_reads_device_fill_compact on the same bytes.
+// column index.  Same packed bytes as msq_pack_reads_device_fill_compact on the same bytes.  The kernel that writes
+// d_compact and *d_presence (which QV strings the reads carry) may still be running on the context's stream: the tables
+// are made and the set's buffers allocated beside it, and the presence word comes back with the pack kernel's flags.
 int msq_pack_compact_resident(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref_start, const int32_t* ref_end, const uint64_t* base_off,
-                              const uint64_t* d_base_off, const uint8_t* d_compact, uint32_t presence, uint32_t pack_flags,
+                              const uint64_t* d_base_off, const uint8_t* d_compact, const uint32_t* d_presence, uint32_t pack_flags,
                               const msq_qv_thresholds* thr_in, msq_packed_dev** out)
 {
     *out = nullptr;
@@ -753,8 +755,10 @@ int msq_pack_compact_resident(msq_ctx* ctx, uint64_t n_reads, const int32_t* ref
         if (e != hipSuccess) return fail(MSQ_ERR_HIP, "pack kernel", e);
     }
     uint64_t res[2] = {~0ull, 0};
+    uint32_t presence = 0;
     {
         hipError_t e = hipMemcpyAsync(res, scratch, 16, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&presence, d_presence, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return fail(MSQ_ERR_HIP, "result copy", e);
     }
