@@ -85,6 +85,9 @@ struct CodeSet {  // a canonical Huffman code, per code length 1..15: first code
     uint16_t first[16], count[16], offs[16];
 };
 
+// timing-experiment switches (tools/inf_exp.sh builds the library with them into minorseq_amd/lib_expN): the scope of the
+// fence in front of a match's copy ("wavefront": no difference measured), INF_WAVES = waves per SIMD to compile for (8: -3 %
+// at the price of spills)
 #ifndef INF_FENCE_SCOPE
 #define INF_FENCE_SCOPE "workgroup"
 #endif
