@@ -754,18 +754,25 @@ extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t f
         }
         const int started = (int)pool.size();
         uint64_t oldest = 0, n_issued = 0;
-        auto poll = [&] {
-            while (oldest < n_issued && hipEventQuery(slot_event[oldest % kSlots]) == hipSuccess) {
+        auto poll = [&] {  // a failed copy (not "not ready yet") ends the upload: nobody may wait for a slot that will not come free
+            while (oldest < n_issued) {
+                const hipError_t q = hipEventQuery(slot_event[oldest % kSlots]);
+                if (q != hipSuccess) {
+                    if (q != hipErrorNotReady) e = q;
+                    (void)hipGetLastError();
+                    break;
+                }
                 ++oldest;
                 fill_limit.store(oldest + kSlots, std::memory_order_release);
             }
         };
         int piece = 0;
         for (uint64_t c = 0; e == hipSuccess && started == workers && c < n_chunks; ++c) {
-            while (ready[c].load(std::memory_order_acquire) < workers) {
+            while (e == hipSuccess && ready[c].load(std::memory_order_acquire) < workers) {
                 poll();
                 std::this_thread::yield();
             }
+            if (e != hipSuccess) break;
             const uint64_t lo = c * kSlot, len = std::min(kSlot, file_bytes - lo);
             e = hipMemcpyAsync(d_file + lo, ring + (c % kSlots) * kSlot, len, hipMemcpyHostToDevice, ctx->copy_stream);
             if (e == hipSuccess) e = hipEventRecord(slot_event[c % kSlots], ctx->copy_stream);
