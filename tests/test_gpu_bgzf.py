@@ -162,6 +162,27 @@ def test_large_image_crosses_in_ring_slots(ctx):
         L.msq_debug_tune(ctx.h, abi.MSQ_TUNE_BAM_PIECES, 3)
 
 
+def test_plain_upload_path(monkeypatch):
+    """MSQ_BAM_UPLOAD_THREADS=0: the image crosses in one hipMemcpyAsync per piece straight from the caller's pages (what a
+    context does that cannot have pinned memory), the same bytes."""
+    monkeypatch.setenv("MSQ_BAM_UPLOAD_THREADS", "0")
+    c = device.Ctx(0)
+    try:
+        rng = np.random.default_rng(29)
+        parts = [member(rng.integers(0, 64, int(rng.integers(1000, 60000))).astype(np.uint8).tobytes(), level=int(rng.integers(1, 10))) for _ in range(120)]
+        blob = b"".join(parts) + member(b"")
+        assert len(blob) > 2 << 20
+        members = scan(blob)
+        want = b"".join(zlib.decompress(blob[m[0]:m[0] + m[2]], -15) for m in members)
+        L = abi.lib()
+        abi.check(L.msq_debug_tune(c.h, abi.MSQ_TUNE_BAM_PIECE_MIN_BYTES, 0))
+        for pieces in (1, 3):
+            abi.check(L.msq_debug_tune(c.h, abi.MSQ_TUNE_BAM_PIECES, pieces))
+            assert inflate_device(c, blob, members) == want
+    finally:
+        c.close()
+
+
 def test_bam_shaped_members(ctx, tmp_path):
     """Members the way a BAM writer makes them: 65280-byte payloads of records (packed bases, quality bytes, names, tags)
     at level 1 -- long literal runs that end in a length code with extra bits right at the edge of the speculative window
