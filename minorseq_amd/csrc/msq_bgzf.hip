@@ -702,7 +702,7 @@ extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t f
     if (workers > 0)  // a piece ends where a slot does
         for (int k = 0; k + 1 < n_pieces; ++k) ctx->staged_upto[k] = ctx->staged_upto[k] / kSlot * kSlot;
     char* const ring = (char*)ctx->pinned_ring;
-    ctx->stage_thread = new (std::nothrow) std::thread([ctx, file, file_bytes, d_file, n_pieces, workers, ring] {
+    auto upload = [ctx, file, file_bytes, d_file, n_pieces, workers, ring] {
         hipError_t e = hipSetDevice(ctx->device);
         auto give_up = [&](hipError_t err) {
             ctx->staged_err.store((int)err);
@@ -794,7 +794,12 @@ extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t f
         for (hipEvent_t ev : slot_event)
             if (ev) (void)hipEventDestroy(ev);
         if (e != hipSuccess || started != workers) give_up(e != hipSuccess ? e : hipErrorOutOfMemory);
-    });
+    };
+    try {
+        ctx->stage_thread = new std::thread(upload);
+    } catch (...) {  // no memory for the object, or no thread to be had (std::system_error)
+        ctx->stage_thread = nullptr;
+    }
     if (!ctx->stage_thread) {
         msq_bgzf_drop_staged(ctx);
         return msq_fail(MSQ_ERR_NOMEM, "msq_bgzf_stage_file: cannot start the copy thread");
