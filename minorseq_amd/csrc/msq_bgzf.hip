@@ -28,6 +28,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <new>
 #include <thread>
 #include <vector>
@@ -725,8 +726,9 @@ extern "C" int msq_bgzf_stage_file(msq_ctx* ctx, const uint8_t* file, uint64_t f
         // filled once the chunk kSlots before it has crossed (fill_limit).  This thread issues the DMAs and the pieces'
         // events.  `stop` ends the workers early when a HIP call has failed.
         const uint64_t n_chunks = (file_bytes + kSlot - 1) / kSlot;
-        std::vector<std::atomic<int>> ready(n_chunks);
-        for (auto& r : ready) r.store(0);
+        std::unique_ptr<std::atomic<int>[]> ready(new (std::nothrow) std::atomic<int>[n_chunks]);
+        if (!ready) return give_up(hipErrorOutOfMemory);
+        for (uint64_t c = 0; c < n_chunks; ++c) ready[c].store(0);
         std::atomic<uint64_t> fill_limit{(uint64_t)kSlots};
         std::atomic<bool> stop{false};
         hipEvent_t slot_event[kSlots] = {};
